@@ -1,0 +1,157 @@
+/*
+ * odamd.h -- C ABI of libodamd.so, the MI355X (gfx950) kernels for the YOLOv7 hot path.
+ *
+ * The reference (TWK2022/ObjectDetection) is pure Python and has no FFI of its own, so each
+ * entry point below names the reference function whose arithmetic it replaces (file:line,
+ * relative to the reference tree).  Conventions:
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the library allocates nothing: callers pass outputs and a workspace (sizes from the
+ *     *_workspace_bytes queries); it keeps no mutable global state and is re-entrant;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work, they never
+ *     synchronise;
+ *   - return value: 0 on success, a negative ODAMD_E_* code for a rejected argument,
+ *     a positive hipError_t if a launch failed.  Nothing throws across the boundary.
+ */
+#ifndef ODAMD_H
+#define ODAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODAMD_OK 0
+#define ODAMD_E_ARG (-1)       /* null pointer / non-positive size / unsupported value */
+#define ODAMD_E_ALIGN (-2)     /* pointer or channel count violates the stated alignment */
+#define ODAMD_E_WORKSPACE (-3) /* workspace too small */
+#define ODAMD_E_SHAPE (-4)     /* shapes inconsistent with each other */
+
+#define ODAMD_DTYPE_F32 0
+#define ODAMD_DTYPE_BF16 1
+
+/* ABI version of this header; bumped on any signature change. */
+int odamd_abi_version(void);
+/* Human-readable text for a return code (static storage). */
+const char* odamd_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Box decode.  Replaces decode.forward (model/layer.py:273-293) and, with deploy != 0, the
+ * sigmoid of deploy.forward (model/layer.py:302-305).
+ *
+ * head[i]   : raw output of head i, float32, the reference's (B, A, H_i, W_i, K) tensor, which
+ *             is the NCHW conv output reinterpreted without a permute (model/layer.py:235).
+ * out       : (B, R, K) float32, R = A * sum_i H_i*W_i, rows ordered scale0[a,y,x], scale1, scale2.
+ * anchor_px : (3, A, 2) float32 HOST array, anchor * input_size already multiplied in float32.
+ * stride    : (3) float32 HOST array, input_size / H_i.
+ * deploy    : 0 -> channels 4: copied (training graph); 1 -> sigmoid applied to channels 4:.
+ */
+typedef struct {
+    const float* head[3];
+    int h[3];
+    int w[3];
+    float stride[3];
+    float anchor_px[3][4][2]; /* up to 4 anchors per scale */
+    int n_anchor;             /* A, 1..4 */
+    int batch;                /* B */
+    int kdim;                 /* K = 5 + classes */
+    int deploy;
+} odamd_decode_desc;
+
+int odamd_decode(const odamd_decode_desc* d, float* out, void* stream);
+
+/* Backward of odamd_decode with deploy == 0: grad wrt the raw head tensors given grad wrt the
+ * decoded tensor and the raw heads (autograd of model/layer.py:279-286).
+ * grad_head[i] has the shape of head[i]. */
+int odamd_decode_backward(const odamd_decode_desc* d, const float* grad_out, float* const grad_head[3],
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Post-processing.  Replaces predict_class._decode / _nms / iou (predict.py:67-92, :33-41)
+ * for a whole batch: (1) x_min = cx - w/2, y_min = cy - h/2; (2) keep conf > conf_thr and
+ * x_min > 0 and y_min > 0; (3) score = conf * max(cls), order by descending score (ties:
+ * descending row index); (4) greedy class-agnostic NMS, candidate survives a kept box iff
+ * IoU < iou_thr evaluated in float32 with the reference's operation order; (5) kept rows
+ * converted back to cx,cy and scaled by (xs, ys) per image.
+ *
+ * pred      : (B, R, K) float32 deployed predictions (not modified).
+ * scale_xy  : (B, 2) float32 device array {image_w/input_size, image_h/input_size}, or NULL for 1.
+ * n_pad     : power of two >= the largest candidate count of any image (R rounded up is always
+ *             safe and needs no host sync); 0 selects that safe bound.
+ * out_rows  : (B, max_keep, K) float32, kept rows in keep order (may be NULL to skip step 5).
+ * out_idx   : (B, max_keep) int32, row index into pred of every kept box, in keep order.
+ * out_count : (B) int32 number of kept boxes (may exceed max_keep; only max_keep are stored).
+ * cand_count: (B) int32 number of candidates that passed step (2) (may be NULL).
+ */
+size_t odamd_postprocess_workspace_bytes(int batch, int rows, int kdim, int n_pad);
+
+int odamd_postprocess(const float* pred, int batch, int rows, int kdim, float conf_thr, float iou_thr,
+                      const float* scale_xy, int n_pad, float* out_rows, int* out_idx, int* out_count,
+                      int* cand_count, int max_keep, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same chain fed from the three RAW head tensors: decode + deploy-sigmoid are evaluated on the
+ * fly, so the (B,R,K) tensor is never written (model/layer.py:273-305 + predict.py:67-92).
+ * out_rows holds fully decoded + deployed rows of the kept boxes. */
+int odamd_postprocess_heads(const odamd_decode_desc* d, float conf_thr, float iou_thr, const float* scale_xy,
+                            int n_pad, float* out_rows, int* out_idx, int* out_count, int* cand_count,
+                            int max_keep, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Building blocks of the chain, exported for tests and for callers that bring their own
+ * candidate set.  boxes: (n) float4 {x_min,y_min,w,h}; bit j of mask word (i, j/64) is set
+ * iff j > i and not (IoU(i,j) < iou_thr).  predict.py:33-41. */
+int odamd_iou_mask(const float* boxes_xywh, int n, float iou_thr, uint64_t* mask, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution block.  Replaces cbs.forward in eval mode (model/layer.py:12-16): Conv2d without
+ * bias, BatchNorm folded by the caller into per-channel (scale, shift), SiLU.  Also serves
+ * head.forward (model/layer.py:234-236) with act = 0 and NCHW float32 output.
+ *
+ * Activations are NHWC ("channels last"): element (b, y, x, c) of a tensor lives at
+ * base[((b*H + y)*W + x)*ld + c], ld >= C.  A concat (model/layer.py:25-27) is therefore a
+ * set of producers writing at channel offsets of one buffer: pass y = buffer + offset and
+ * y_ld = total channels.
+ */
+typedef struct {
+    const void* x;     /* input activations, dtype `dtype`, NHWC with pixel stride x_ld */
+    const void* w;     /* packed weights [cout][ky][kx][cin], dtype `dtype` */
+    const float* scale;/* [cout] float32 (BN gamma/sqrt(var+eps)), NULL = 1 */
+    const float* shift;/* [cout] float32 (BN beta - mean*scale, or conv bias), NULL = 0 */
+    void* y;           /* output */
+    int batch, h, w_in;/* input spatial size */
+    int cin, cout;     /* cin % 16 == 0 unless first-layer kernel; any cout */
+    int x_ld, y_ld;    /* pixel strides in elements (NHWC), y_ld ignored for NCHW output */
+    int ksize;         /* 1 or 3, padding (ksize-1)/2 */
+    int stride;        /* 1 or 2 */
+    int act;           /* 0 none, 1 SiLU */
+    int dtype;         /* ODAMD_DTYPE_* of x, w (and of y when out_nchw_f32 == 0) */
+    int in_pool2;      /* 1: input is max-pooled 2x2/2 on the fly (mp.maxpool0, model/layer.py:140) */
+    int out_nchw_f32;  /* 1: y is float32 NCHW (B, cout, Ho, Wo) -- the head layout */
+} odamd_conv_desc;
+
+int odamd_conv_forward(const odamd_conv_desc* d, void* stream);
+
+/* First layer: float32 NCHW image (B,3,H,W) -> NHWC activations; replaces cbs0 of
+ * yolov7.forward (model/yolov7.py:114) in eval mode.  w: [cout][ky][kx][3] float32. */
+int odamd_conv_first_forward(const float* image, const float* w, const float* scale, const float* shift,
+                             void* y, int batch, int h, int w_in, int cout, int y_ld, int dtype, void* stream);
+
+/* MaxPool2d(2,2) (model/layer.py:125), three stride-1 max pools k=5,9,13 of one tensor
+ * (model/layer.py:215-217) and nearest Upsample x2 (model/yolov7.py:32), all NHWC, each
+ * able to write into a channel slice of a wider buffer. */
+int odamd_maxpool2_forward(const void* x, void* y, int batch, int h, int w, int c, int x_ld, int y_ld,
+                           int dtype, void* stream);
+int odamd_spp_pool3_forward(const void* x, void* y5, void* y9, void* y13, int batch, int h, int w, int c,
+                            int x_ld, int y_ld, int dtype, void* stream);
+int odamd_upsample2_forward(const void* x, void* y, int batch, int h, int w, int c, int x_ld, int y_ld,
+                            int dtype, void* stream);
+/* Layout converters between NCHW float32 (the module API) and NHWC activations. */
+int odamd_nchw_to_nhwc(const float* x, void* y, int batch, int c, int h, int w, int y_ld, int dtype,
+                       void* stream);
+int odamd_nhwc_to_nchw(const void* x, float* y, int batch, int c, int h, int w, int x_ld, int dtype,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODAMD_H */

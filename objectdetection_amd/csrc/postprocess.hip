@@ -1,0 +1,599 @@
+// Box decode, confidence filter, score sort and greedy NMS for gfx950.
+//
+// All arithmetic here is float32 with one rounding per operation (this file is compiled with
+// -ffp-contract=off) so that, given identical inputs, the kept-box indices equal those of the
+// numpy code in the reference (predict.py:33-41, :67-92) bit for bit.
+//
+// Kernels (all HBM/latency bound, no matrix work):
+//   decode_kernel         heads (NCHW-flat) -> (B,R,K) decoded rows            elementwise stream
+//   decode_bwd_kernel     autograd of the above
+//   filter_kernel<SRC>    rows -> {row box, compacted 64-bit sort key, count}  ballot compaction
+//   bitonic_*             per-image descending sort of the keys (LDS + global stages)
+//   gather_sorted_kernel  sorted keys -> sorted boxes / row ids
+//   iou_mask_kernel       64x64 tiles of the suppression bitmask, column boxes staged in LDS
+//   nms_scan_kernel       one workgroup per image walks the mask in score order
+//   emit_rows_kernel      kept rows -> (cx,cy,w,h,...) scaled to the source image
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+#include "odamd.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ float sigmoid_f32(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------------
+struct DecodeGeom {
+    const float* head[3];
+    int h[3], w[3];
+    int rows_before[3];  // rows of earlier scales within one image
+    float stride[3];
+    float anchor[3][4][2];
+    int n_anchor, kdim, rows, deploy;
+};
+
+// One decoded element.  k: channel within the row, (a, y, x): anchor and grid cell.
+__device__ __forceinline__ float decode_value(const DecodeGeom& g, int s, int k, int a, int y, int x, float raw) {
+    if (k < 4) {
+        const float t = sigmoid_f32(raw);
+        if (k == 0) return (2.0f * t - 0.5f + (float)x) * g.stride[s];
+        if (k == 1) return (2.0f * t - 0.5f + (float)y) * g.stride[s];
+        return (4.0f * (t * t)) * g.anchor[s][a][k - 2];
+    }
+    return g.deploy ? sigmoid_f32(raw) : raw;
+}
+
+__global__ void __launch_bounds__(256) decode_kernel(DecodeGeom g, float* __restrict__ out) {
+    const int s = blockIdx.y, b = blockIdx.z;
+    const int hw = g.h[s] * g.w[s];
+    const int n = g.n_anchor * hw * g.kdim;
+    const float* src = g.head[s] + (size_t)b * n;
+    float* dst = out + ((size_t)b * g.rows + g.rows_before[s]) * g.kdim;
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n; f += gridDim.x * blockDim.x) {
+        const int row = f / g.kdim, k = f - row * g.kdim;
+        const int a = row / hw, cell = row - a * hw;
+        const int y = cell / g.w[s], x = cell - y * g.w[s];
+        dst[f] = decode_value(g, s, k, a, y, x, src[f]);
+    }
+}
+
+// d raw = d out * d(decode)/d raw.  Channels >= 4 pass through (deploy == 0 in training).
+__global__ void __launch_bounds__(256) decode_bwd_kernel(DecodeGeom g, const float* __restrict__ gout,
+                                                         float* gh0, float* gh1, float* gh2) {
+    const int s = blockIdx.y, b = blockIdx.z;
+    const int hw = g.h[s] * g.w[s];
+    const int n = g.n_anchor * hw * g.kdim;
+    const float* src = g.head[s] + (size_t)b * n;
+    const float* go = gout + ((size_t)b * g.rows + g.rows_before[s]) * g.kdim;
+    float* dst = (s == 0 ? gh0 : s == 1 ? gh1 : gh2) + (size_t)b * n;
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n; f += gridDim.x * blockDim.x) {
+        const int row = f / g.kdim, k = f - row * g.kdim;
+        float gv = go[f];
+        if (k < 4) {
+            const float t = sigmoid_f32(src[f]);
+            const float dt = t * (1.0f - t);
+            if (k < 2) {
+                gv = gv * (2.0f * g.stride[s]) * dt;
+            } else {
+                const int a = row / hw;
+                gv = gv * (8.0f * t * g.anchor[s][a][k - 2]) * dt;
+            }
+        }
+        dst[f] = gv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// filter: rows -> row boxes + compacted sort keys
+// ------------------------------------------------------------------------------------------
+// Sort key: high word = score bits mapped so that unsigned order == float order, low word = row
+// index.  A descending sort of the keys is "descending score, then descending row index".
+// Key 0 never occurs for a real candidate and marks padding.
+__device__ __forceinline__ u64 make_key(float score, int row) {
+    if (score == 0.0f) score = 0.0f;  // -0 -> +0, numpy orders them as equal
+    uint32_t u = __float_as_uint(score);
+    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+    return ((u64)u << 32) | (uint32_t)row;
+}
+
+constexpr int FILTER_THREADS = 256;
+
+// SRC == 0: `rows` is the deployed (B,R,K) tensor.  SRC == 1: rows come from the raw heads and
+// are decoded + sigmoided while they sit in LDS.
+// Each workgroup stages `rows_stage` whole rows in LDS with coalesced loads (row stride padded
+// to an odd number of words so the per-row walk below is bank-conflict free), then one lane
+// per row evaluates predict.py:68-70,83.
+template <int SRC>
+__global__ void __launch_bounds__(FILTER_THREADS)
+filter_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdim, int rows_stage, float conf_thr,
+              float4* __restrict__ rowbox, u64* __restrict__ keys, int n_pad, int* __restrict__ count) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.y;
+    const int row0 = blockIdx.x * rows_stage;
+    const int nrow = min(rows_stage, rows - row0);
+    if (nrow <= 0) return;
+    const int ldk = kdim | 1;
+    // stage rows [row0, row0+nrow)
+    if (SRC == 0) {
+        const float* src = pred + ((size_t)b * rows + row0) * kdim;
+        for (int f = threadIdx.x; f < nrow * kdim; f += FILTER_THREADS) {
+            const int r = f / kdim, k = f - r * kdim;
+            lds[r * ldk + k] = src[f];
+        }
+    } else {
+        for (int f = threadIdx.x; f < nrow * kdim; f += FILTER_THREADS) {
+            const int r = f / kdim, k = f - r * kdim;
+            const int row = row0 + r;
+            const int s = row >= g.rows_before[2] ? 2 : (row >= g.rows_before[1] ? 1 : 0);
+            const int lrow = row - g.rows_before[s];
+            const int hw = g.h[s] * g.w[s];
+            const int a = lrow / hw, cell = lrow - a * hw;
+            const int y = cell / g.w[s], x = cell - y * g.w[s];
+            const float raw = g.head[s][((size_t)b * g.n_anchor * hw + lrow) * kdim + k];
+            lds[r * ldk + k] = decode_value(g, s, k, a, y, x, raw);
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < ((nrow + 63) & ~63); r += FILTER_THREADS) {
+        bool pass = false;
+        u64 key = 0;
+        if (r < nrow) {
+            const float* p = lds + r * ldk;
+            const float bw = p[2], bh = p[3];
+            const float xmin = p[0] - bw / 2.0f;
+            const float ymin = p[1] - bh / 2.0f;
+            const float conf = p[4];
+            pass = (conf > conf_thr) && (xmin > 0.0f) && (ymin > 0.0f);
+            if (pass) {
+                float m = p[5];
+                for (int k = 6; k < kdim; ++k) m = fmaxf(m, p[k]);
+                key = make_key(conf * m, row0 + r);
+                rowbox[(size_t)b * rows + row0 + r] = make_float4(xmin, ymin, bw, bh);
+            }
+        }
+        // wave-level compaction: one atomic per wave, lanes take consecutive slots
+        const u64 bal = __ballot(pass);
+        if (bal) {
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&count[b], __popcll(bal));
+            base = __shfl(base, 0);
+            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pass && pos < n_pad) keys[(size_t)b * n_pad + pos] = key;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// bitonic sort, descending, n_pad keys per image (power of two), padding keys are 0
+// ------------------------------------------------------------------------------------------
+constexpr int SORT_CHUNK = 4096;  // keys per workgroup in the LDS stages (32 KiB)
+constexpr int SORT_THREADS = 512;
+
+// Descending network: in block (i & k) == 0 the larger key goes to the lower index.
+__device__ __forceinline__ void cmpex(u64& lo, u64& hi, bool desc) {
+    const bool sw = desc ? (lo < hi) : (lo > hi);
+    if (sw) { const u64 t = lo; lo = hi; hi = t; }
+}
+
+// All stages with k <= chunk (FULL) or the j < chunk tail of stage k_outer (!FULL), in LDS.
+template <bool FULL>
+__global__ void __launch_bounds__(SORT_THREADS) bitonic_lds_kernel(u64* __restrict__ keys, int n_pad, int chunk, int k_outer) {
+    __shared__ u64 s[SORT_CHUNK];
+    u64* base = keys + (size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * chunk;
+    const int g0 = blockIdx.x * chunk;
+    for (int i = threadIdx.x; i < chunk; i += SORT_THREADS) s[i] = base[i];
+    __syncthreads();
+    for (int k = FULL ? 2 : k_outer; k <= (FULL ? chunk : k_outer); k <<= 1) {
+        for (int j = min(k, chunk) >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < chunk / 2; t += SORT_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const bool desc = (((g0 + i) & k) == 0);
+                u64 a = s[i], c = s[i + j];
+                cmpex(a, c, desc);
+                s[i] = a;
+                s[i + j] = c;
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < chunk; i += SORT_THREADS) base[i] = s[i];
+}
+
+// One compare-exchange stage (k, j) with j >= chunk, straight in global memory.
+__global__ void __launch_bounds__(256) bitonic_global_kernel(u64* __restrict__ keys, int n_pad, int k, int j) {
+    u64* base = keys + (size_t)blockIdx.y * n_pad;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_pad / 2) return;
+    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+    const bool desc = ((i & k) == 0);
+    u64 a = base[i], c = base[i + j];
+    const bool sw = desc ? (a < c) : (a > c);
+    if (sw) { base[i] = c; base[i + j] = a; }
+}
+
+__global__ void __launch_bounds__(256)
+gather_sorted_kernel(const u64* __restrict__ keys, const float4* __restrict__ rowbox, const int* __restrict__ count,
+                     int rows, int n_pad, float4* __restrict__ sbox, int* __restrict__ srow) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad || i >= count[b]) return;
+    const int row = (int)(uint32_t)keys[(size_t)b * n_pad + i];
+    srow[(size_t)b * n_pad + i] = row;
+    sbox[(size_t)b * n_pad + i] = rowbox[(size_t)b * rows + row];
+}
+
+// ------------------------------------------------------------------------------------------
+// IoU bitmask + greedy scan
+// ------------------------------------------------------------------------------------------
+// predict.py:35-41 for boxes (x_min, y_min, w, h); returns true when the candidate is
+// suppressed, i.e. NOT (iou < thr).  NaN (0/0 for two empty boxes) suppresses, as in numpy.
+__device__ __forceinline__ bool suppresses(const float4 a, const float4 c, float thr) {
+    const float x1 = fmaxf(a.x, c.x);
+    const float y1 = fmaxf(a.y, c.y);
+    const float x2 = fminf(a.x + a.z, c.x + c.z);
+    const float y2 = fminf(a.y + a.w, c.y + c.w);
+    const float inter = fmaxf(x2 - x1, 0.0f) * fmaxf(y2 - y1, 0.0f);
+    const float uni = a.z * a.w + c.z * c.w - inter;
+    const float iou = inter / uni;
+    return !(iou < thr);
+}
+
+constexpr int MASK_WAVES = 4;
+
+// Grid: x = groups of MASK_WAVES column tiles, y = row tiles of this chunk, z = image.
+// Wave w of a workgroup owns the 64x64 tile (row tile, column tile 4*bx + w): lane i holds row
+// box i in registers, the 64 column boxes sit in the wave's 1 KiB LDS slice and are read as
+// broadcasts.  Rows already suppressed by earlier chunks (bit set in `removed`) are skipped.
+__global__ void __launch_bounds__(64 * MASK_WAVES)
+iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, const u64* __restrict__ removed,
+                int n_pad, int row_begin, float thr, u64* __restrict__ mask, size_t mask_stride_img) {
+    __shared__ float4 cols[MASK_WAVES][64];
+    const int b = blockIdx.z;
+    const int n = count ? min(count[b], n_pad) : n_pad;
+    const int words = n_pad >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rt = (row_begin >> 6) + blockIdx.y;   // global row tile
+    const int ct = blockIdx.x * MASK_WAVES + wave;  // global column tile
+    if (rt * 64 >= n) return;                       // uniform per workgroup
+    const bool active = (ct >= rt) && (ct * 64 < n) && (ct < words);
+    const float4* boxes = sbox + (size_t)b * n_pad;
+    if (active) cols[wave][lane] = (ct * 64 + lane < n) ? boxes[ct * 64 + lane] : make_float4(0, 0, 0, 0);
+    __syncthreads();
+    if (!active) return;
+    const int i = rt * 64 + lane;
+    u64 word = 0;
+    bool live = i < n;
+    if (live && removed) live = !((removed[(size_t)b * words + rt] >> lane) & 1ull);
+    if (live) {
+        const float4 a = boxes[i];
+        const int jmax = min(64, n - ct * 64);
+#pragma unroll 8
+        for (int j = 0; j < jmax; ++j) {
+            const bool s = suppresses(a, cols[wave][j], thr);
+            word |= (u64)(s && (ct * 64 + j > i)) << j;
+        }
+    }
+    mask[(size_t)b * mask_stride_img + (size_t)(i - row_begin) * words + ct] = word;
+}
+
+constexpr int SCAN_THREADS = 256;
+
+// One workgroup per image.  `removed` (n_pad bits) lives in LDS for the chunk and in global
+// memory between chunks.  Per 64-row tile: wave 0 resolves the tile serially from its 64
+// diagonal words (uniform scalar work), then all threads OR the kept rows' words into the
+// later part of `removed`.
+__global__ void __launch_bounds__(SCAN_THREADS)
+nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int* __restrict__ count,
+                const int* __restrict__ srow, u64* __restrict__ removed_g, int n_pad, int row_begin, int row_end,
+                int* __restrict__ keep_idx, int* __restrict__ keep_count, int max_keep) {
+    extern __shared__ __attribute__((aligned(16))) u64 removed[];
+    __shared__ u64 kept_bits;
+    __shared__ int kept_total;
+    const int b = blockIdx.x;
+    const int n = count ? min(count[b], n_pad) : n_pad;
+    if (row_begin >= n) return;
+    const int words = n_pad >> 6;
+    const int nwords = (n + 63) >> 6;
+    const u64* m = mask + (size_t)b * mask_stride_img;
+    u64* rg = removed_g + (size_t)b * words;
+    for (int w = threadIdx.x; w < nwords; w += SCAN_THREADS) removed[w] = rg[w];
+    if (threadIdx.x == 0) kept_total = keep_count[b];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int t_end = (min(row_end, n) + 63) >> 6;
+    for (int t = row_begin >> 6; t < t_end; ++t) {
+        if (threadIdx.x < 64) {
+            const int i = t * 64 + lane;
+            const u64 diag = (i < n) ? m[(size_t)(i - row_begin) * words + t] : 0ull;
+            const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
+            u64 alive = ~removed[t];
+            if (n - t * 64 < 64) alive &= (1ull << (n - t * 64)) - 1ull;
+            u64 kept = 0;
+#pragma unroll
+            for (int q = 0; q < 64; ++q) {
+                const u64 dq = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)dhi, q) << 32) |
+                               (uint32_t)__builtin_amdgcn_readlane((int)dlo, q);
+                if ((alive >> q) & 1ull) {
+                    kept |= 1ull << q;
+                    alive &= ~dq;
+                }
+            }
+            const int base = kept_total;
+            if ((kept >> lane) & 1ull) {
+                const int pos = base + __popcll(kept & ((1ull << lane) - 1ull));
+                if (pos < max_keep) keep_idx[(size_t)b * max_keep + pos] = srow[(size_t)b * n_pad + i];
+            }
+            if (lane == 0) {
+                kept_bits = kept;
+                kept_total = base + __popcll(kept);
+                removed[t] |= ~kept;  // every row of a finished tile is decided
+            }
+        }
+        __syncthreads();
+        const u64 kept = kept_bits;
+        if (kept) {
+            for (int w = t + 1 + threadIdx.x; w < nwords; w += SCAN_THREADS) {
+                u64 acc = 0;
+                u64 kk = kept;
+                while (kk) {
+                    const int q = __ffsll((long long)kk) - 1;
+                    kk &= kk - 1;
+                    acc |= m[(size_t)(t * 64 + q - row_begin) * words + w];
+                }
+                removed[w] |= acc;
+            }
+        }
+        __syncthreads();
+    }
+    for (int w = threadIdx.x; w < nwords; w += SCAN_THREADS) rg[w] = removed[w];
+    if (threadIdx.x == 0) keep_count[b] = kept_total;
+}
+
+// Kept rows -> output rows (predict.py:74-79).  SRC as in filter_kernel.
+template <int SRC>
+__global__ void __launch_bounds__(256)
+emit_rows_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdim, const int* __restrict__ keep_idx,
+                 const int* __restrict__ keep_count, int max_keep, const float* __restrict__ scale_xy,
+                 float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int nk = min(keep_count[b], max_keep);
+    const float xs = scale_xy ? scale_xy[2 * b] : 1.0f;
+    const float ys = scale_xy ? scale_xy[2 * b + 1] : 1.0f;
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nk * kdim; f += gridDim.x * blockDim.x) {
+        const int j = f / kdim, k = f - j * kdim;
+        const int row = keep_idx[(size_t)b * max_keep + j];
+        float v[4];
+        const int k0 = k < 4 ? 0 : k, k1 = k < 4 ? 4 : k + 1;
+        float val = 0.f;
+        for (int kk = k0; kk < k1; ++kk) {
+            float x;
+            if (SRC == 0) {
+                x = pred[((size_t)b * rows + row) * kdim + kk];
+            } else {
+                const int s = row >= g.rows_before[2] ? 2 : (row >= g.rows_before[1] ? 1 : 0);
+                const int lrow = row - g.rows_before[s];
+                const int hw = g.h[s] * g.w[s];
+                const int a = lrow / hw, cell = lrow - a * hw;
+                const int y = cell / g.w[s], xx = cell - y * g.w[s];
+                x = decode_value(g, s, kk, a, y, xx, g.head[s][((size_t)b * g.n_anchor * hw + lrow) * kdim + kk]);
+            }
+            if (k < 4) v[kk] = x; else val = x;
+        }
+        if (k < 4) {
+            // x_min = cx - w/2 ; cx' = x_min + w/2 ; scaled.  Same roundings as the reference.
+            const float half = v[2 + (k & 1)] / 2.0f;
+            if (k < 2) val = ((v[k] - half) + half) * (k == 0 ? xs : ys);
+            else val = v[k] * (k == 2 ? xs : ys);
+        }
+        out[((size_t)b * max_keep + j) * kdim + k] = val;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+int next_pow2(int v) {
+    int p = 64;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+int fill_geom(const odamd_decode_desc* d, DecodeGeom* g) {
+    if (!d || d->n_anchor < 1 || d->n_anchor > 4 || d->batch < 1 || d->kdim < 6) return ODAMD_E_ARG;
+    int rows = 0;
+    for (int s = 0; s < 3; ++s) {
+        if (!d->head[s] || d->h[s] < 1 || d->w[s] < 1) return ODAMD_E_ARG;
+        g->head[s] = d->head[s];
+        g->h[s] = d->h[s];
+        g->w[s] = d->w[s];
+        g->stride[s] = d->stride[s];
+        g->rows_before[s] = rows;
+        rows += d->n_anchor * d->h[s] * d->w[s];
+        for (int a = 0; a < 4; ++a)
+            for (int c = 0; c < 2; ++c) g->anchor[s][a][c] = d->anchor_px[s][a][c];
+    }
+    g->n_anchor = d->n_anchor;
+    g->kdim = d->kdim;
+    g->rows = rows;
+    g->deploy = d->deploy;
+    return ODAMD_OK;
+}
+
+struct Workspace {
+    u64* keys;
+    float4* rowbox;
+    float4* sbox;
+    int* srow;
+    u64* removed;
+    u64* mask;
+    int* count;
+    size_t mask_stride_img;  // words per image
+    int chunk_rows;
+    size_t total;
+};
+
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+Workspace carve(char* base, int batch, int rows, int n_pad) {
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
+    w.keys = (u64*)take((size_t)batch * n_pad * 8);
+    w.rowbox = (float4*)take((size_t)batch * rows * 16);
+    w.sbox = (float4*)take((size_t)batch * n_pad * 16);
+    w.srow = (int*)take((size_t)batch * n_pad * 4);
+    w.removed = (u64*)take((size_t)batch * (n_pad / 64) * 8);
+    w.count = (int*)take((size_t)batch * 4);
+    // mask chunk: at most 16 MiB per image, whole 64-row tiles
+    long long chunk = (16ll << 20) * 8 / n_pad;
+    chunk = (chunk / 64) * 64;
+    if (chunk < 64) chunk = 64;
+    if (chunk > n_pad) chunk = n_pad;
+    w.chunk_rows = (int)chunk;
+    w.mask_stride_img = (size_t)chunk * (n_pad / 64);
+    w.mask = (u64*)take((size_t)batch * w.mask_stride_img * 8);
+    w.total = off;
+    return w;
+}
+
+int sort_keys(u64* keys, int batch, int n_pad, hipStream_t st) {
+    const int chunk = n_pad < SORT_CHUNK ? n_pad : SORT_CHUNK;
+    dim3 grid_l(n_pad / chunk, batch);
+    bitonic_lds_kernel<true><<<grid_l, SORT_THREADS, 0, st>>>(keys, n_pad, chunk, 0);
+    for (int k = chunk * 2; k <= n_pad; k <<= 1) {
+        for (int j = k >> 1; j >= chunk; j >>= 1)
+            bitonic_global_kernel<<<dim3((n_pad / 2 + 255) / 256, batch), 256, 0, st>>>(keys, n_pad, k, j);
+        bitonic_lds_kernel<false><<<grid_l, SORT_THREADS, 0, st>>>(keys, n_pad, chunk, k);
+    }
+    return (int)hipGetLastError();
+}
+
+int run_nms(const Workspace& w, const int* count, int batch, int n_pad, float iou_thr, int* out_idx, int* out_count,
+            int max_keep, hipStream_t st) {
+    const int words = n_pad / 64;
+    for (int r0 = 0; r0 < n_pad; r0 += w.chunk_rows) {
+        const int r1 = r0 + w.chunk_rows < n_pad ? r0 + w.chunk_rows : n_pad;
+        dim3 grid((words + MASK_WAVES - 1) / MASK_WAVES, (r1 - r0) / 64, batch);
+        iou_mask_kernel<<<grid, 64 * MASK_WAVES, 0, st>>>(w.sbox, count, w.removed, n_pad, r0, iou_thr, w.mask,
+                                                           w.mask_stride_img);
+        nms_scan_kernel<<<batch, SCAN_THREADS, (size_t)words * 8, st>>>(w.mask, w.mask_stride_img, count, w.srow,
+                                                                        w.removed, n_pad, r0, r1, out_idx, out_count,
+                                                                        max_keep);
+    }
+    return (int)hipGetLastError();
+}
+
+template <int SRC>
+int postprocess_impl(const float* pred, const DecodeGeom& g, int batch, int rows, int kdim, float conf_thr,
+                     float iou_thr, const float* scale_xy, int n_pad, float* out_rows, int* out_idx, int* out_count,
+                     int* cand_count, int max_keep, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (batch < 1 || rows < 1 || kdim < 6 || max_keep < 1 || !out_idx || !out_count || !workspace) return ODAMD_E_ARG;
+    if (n_pad == 0) n_pad = next_pow2(rows);
+    if (n_pad < 64 || (n_pad & (n_pad - 1)) || n_pad > (1 << 18)) return ODAMD_E_ARG;
+    if (((uintptr_t)workspace & 255) != 0) return ODAMD_E_ALIGN;
+    Workspace w = carve((char*)workspace, batch, rows, n_pad);
+    if (w.total > workspace_bytes) return ODAMD_E_WORKSPACE;
+    int rc;
+    if ((rc = (int)hipMemsetAsync(w.keys, 0, (size_t)batch * n_pad * 8, st))) return rc;
+    if ((rc = (int)hipMemsetAsync(w.removed, 0, (size_t)batch * (n_pad / 64) * 8, st))) return rc;
+    if ((rc = (int)hipMemsetAsync(w.count, 0, (size_t)batch * 4, st))) return rc;
+    if ((rc = (int)hipMemsetAsync(out_count, 0, (size_t)batch * 4, st))) return rc;
+    // rows staged per workgroup: as many as fit 48 KiB, at most one per thread
+    const int ldk = kdim | 1;
+    int rows_stage = (48 * 1024) / (ldk * 4);
+    if (rows_stage > FILTER_THREADS) rows_stage = FILTER_THREADS;
+    if (rows_stage < 1) return ODAMD_E_ARG;  // more than ~12k classes
+    dim3 fgrid((rows + rows_stage - 1) / rows_stage, batch);
+    filter_kernel<SRC><<<fgrid, FILTER_THREADS, (size_t)rows_stage * ldk * 4, st>>>(
+        pred, g, rows, kdim, rows_stage, conf_thr, w.rowbox, w.keys, n_pad, w.count);
+    if ((rc = sort_keys(w.keys, batch, n_pad, st))) return rc;
+    gather_sorted_kernel<<<dim3((n_pad + 255) / 256, batch), 256, 0, st>>>(w.keys, w.rowbox, w.count, rows, n_pad,
+                                                                           w.sbox, w.srow);
+    if ((rc = run_nms(w, w.count, batch, n_pad, iou_thr, out_idx, out_count, max_keep, st))) return rc;
+    if (cand_count)
+        if ((rc = (int)hipMemcpyAsync(cand_count, w.count, (size_t)batch * 4, hipMemcpyDeviceToDevice, st))) return rc;
+    if (out_rows) {
+        const int gx = (max_keep * kdim + 255) / 256;
+        emit_rows_kernel<SRC><<<dim3(gx > 1024 ? 1024 : gx, batch), 256, 0, st>>>(pred, g, rows, kdim, out_idx,
+                                                                                   out_count, max_keep, scale_xy,
+                                                                                   out_rows);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int odamd_decode(const odamd_decode_desc* d, float* out, void* stream) {
+    DecodeGeom g;
+    int rc = fill_geom(d, &g);
+    if (rc) return rc;
+    if (!out) return ODAMD_E_ARG;
+    int maxn = 0;
+    for (int s = 0; s < 3; ++s) maxn = max(maxn, d->n_anchor * d->h[s] * d->w[s] * d->kdim);
+    int gx = (maxn + 255) / 256;
+    if (gx > 2048) gx = 2048;
+    decode_kernel<<<dim3(gx, 3, d->batch), 256, 0, (hipStream_t)stream>>>(g, out);
+    return (int)hipGetLastError();
+}
+
+int odamd_decode_backward(const odamd_decode_desc* d, const float* grad_out, float* const grad_head[3], void* stream) {
+    DecodeGeom g;
+    int rc = fill_geom(d, &g);
+    if (rc) return rc;
+    if (!grad_out || !grad_head || !grad_head[0] || !grad_head[1] || !grad_head[2] || d->deploy) return ODAMD_E_ARG;
+    int maxn = 0;
+    for (int s = 0; s < 3; ++s) maxn = max(maxn, d->n_anchor * d->h[s] * d->w[s] * d->kdim);
+    int gx = (maxn + 255) / 256;
+    if (gx > 2048) gx = 2048;
+    decode_bwd_kernel<<<dim3(gx, 3, d->batch), 256, 0, (hipStream_t)stream>>>(g, grad_out, grad_head[0], grad_head[1],
+                                                                              grad_head[2]);
+    return (int)hipGetLastError();
+}
+
+size_t odamd_postprocess_workspace_bytes(int batch, int rows, int kdim, int n_pad) {
+    (void)kdim;
+    if (batch < 1 || rows < 1) return 0;
+    if (n_pad == 0) n_pad = next_pow2(rows);
+    return carve(nullptr, batch, rows, n_pad).total;
+}
+
+int odamd_postprocess(const float* pred, int batch, int rows, int kdim, float conf_thr, float iou_thr,
+                      const float* scale_xy, int n_pad, float* out_rows, int* out_idx, int* out_count, int* cand_count,
+                      int max_keep, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!pred) return ODAMD_E_ARG;
+    DecodeGeom g = {};
+    return postprocess_impl<0>(pred, g, batch, rows, kdim, conf_thr, iou_thr, scale_xy, n_pad, out_rows, out_idx,
+                               out_count, cand_count, max_keep, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int odamd_postprocess_heads(const odamd_decode_desc* d, float conf_thr, float iou_thr, const float* scale_xy, int n_pad,
+                            float* out_rows, int* out_idx, int* out_count, int* cand_count, int max_keep,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    DecodeGeom g;
+    int rc = fill_geom(d, &g);
+    if (rc) return rc;
+    g.deploy = 1;
+    return postprocess_impl<1>(nullptr, g, d->batch, g.rows, d->kdim, conf_thr, iou_thr, scale_xy, n_pad, out_rows,
+                               out_idx, out_count, cand_count, max_keep, workspace, workspace_bytes,
+                               (hipStream_t)stream);
+}
+
+int odamd_iou_mask(const float* boxes_xywh, int n, float iou_thr, uint64_t* mask, void* stream) {
+    if (!boxes_xywh || !mask || n < 64 || (n & 63)) return ODAMD_E_ARG;
+    if (((uintptr_t)boxes_xywh & 15) != 0) return ODAMD_E_ALIGN;
+    const int words = n / 64;
+    dim3 grid((words + MASK_WAVES - 1) / MASK_WAVES, words, 1);
+    iou_mask_kernel<<<grid, 64 * MASK_WAVES, 0, (hipStream_t)stream>>>((const float4*)boxes_xywh, nullptr, nullptr, n, 0,
+                                                                       iou_thr, (u64*)mask, 0);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"
