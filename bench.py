@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: YOLOv7-s 640x640 batch-64 bf16 inference (forward + decode + filter +
+NMS) on MI355X, images/sec; one process per GPU (replicas, weak scaling: inference has no
+cross-GPU step).  Prints ONE JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Synthetic data: torch.rand images under generator seed 999, random-init weights of the
+architecture under torch.manual_seed(999) (run.py:75 of the reference uses the same seed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}   # dense peaks
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--batch', type=int, default=64, help='images per GPU per step')
+    p.add_argument('--size', type=int, default=640)
+    p.add_argument('--classes', type=int, default=80)
+    p.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    p.add_argument('--conf', type=float, default=0.5)
+    p.add_argument('--iou', type=float, default=0.5)
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    return p.parse_args()
+
+
+def cpu_baseline(model, a, margs, x_cpu):
+    """The CPU restatement of the same path (oracle), bounded sample, timed on this host."""
+    from oracle import network, postprocess as opost
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(min(cores, 64))
+    used = torch.get_num_threads()
+    sd = {k: v.detach().cpu().float().clone() for k, v in model.state_dict().items()}
+    n_fwd = 2
+    with torch.no_grad():
+        network.yolov7_forward(sd, x_cpu[:1], margs, deploy=True)          # warm-up
+        t0 = time.perf_counter()
+        pred = network.yolov7_forward(sd, x_cpu[:n_fwd], margs, deploy=True).numpy()
+        t_fwd = (time.perf_counter() - t0) / n_fwd
+    t0 = time.perf_counter()
+    rows, kept = opost.predict_decode(pred[0], (a.size, a.size, 3), a.size, a.conf, a.iou)
+    t_post = time.perf_counter() - t0
+    return {'value': 1.0 / (t_fwd + t_post), 'unit': 'images/sec', 'cores': used, 'kind': 'port',
+            'sample': f'{n_fwd} images forward on {used} torch threads ({t_fwd * 1e3:.0f} ms/img) + numpy '
+                      f'decode/NMS of 1 image on 1 core ({t_post:.2f} s, {len(kept)} kept); reference loop is '
+                      'single-threaded Python (predict.py:86-90)',
+            'forward_ms_per_image': t_fwd * 1e3, 'postprocess_s_per_image': t_post}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != a.gpus and rank == 0:
+        print(f'# note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from objectdetection_amd import engine, postprocess
+    from objectdetection_amd.model.yolov7 import yolov7
+    from oracle import patterns
+
+    margs = patterns.default_args(input_size=a.size, output_class=a.classes)
+    torch.manual_seed(999)
+    model = yolov7(margs).to(dev).eval()
+    engine.set_compute_dtype(a.dtype)
+    gen = torch.Generator().manual_seed(999 + rank)
+    x_cpu = torch.rand(a.batch, 3, a.size, a.size, generator=gen)
+    x = x_cpu.to(dev)
+
+    def step():
+        heads = model.head_tensors(x)
+        return postprocess.postprocess_heads(heads, a.size, margs.anchor, a.conf, a.iou)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        res = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = world * a.batch * a.steps / dt
+
+    out = None
+    if rank == 0:
+        # ---- per-kernel device times (HIP events on the launch stream) -> roofline of the dominant kernel
+        plan = model._plan(x)
+        prof = plan.profile(x, repeats=5)
+        fam = {}
+        for m in prof:
+            f = fam.setdefault(m['kernel'], {'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'launches': 0})
+            f['ms'] += m['ms']
+            f['flops'] += m['flops']
+            f['bytes'] += m['bytes']
+            f['launches'] += 1
+        net_ms = sum(m['ms'] for m in prof)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        heads = model.head_tensors(x)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            res = postprocess.postprocess_heads(heads, a.size, margs.anchor, a.conf, a.iou)
+        e1.record()
+        torch.cuda.synchronize()
+        post_ms = e0.elapsed_time(e1) / 5
+        dom_name = max((k for k in fam if fam[k]['flops'] > 0), key=lambda k: fam[k]['ms'])
+        dom = fam[dom_name]
+        t_mfma = dom['flops'] / (MFMA_PEAK_TFLOPS[a.dtype] * 1e12)
+        t_hbm = dom['bytes'] / (HBM_PEAK_GBS * 1e9)
+        if t_mfma >= t_hbm:
+            ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'achieved': ach, 'peak': MFMA_PEAK_TFLOPS[a.dtype], 'unit': 'TFLOP/s'}
+        else:
+            ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
+            roof = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
+        roof.update({'frac': roof['achieved'] / roof['peak'], 'traffic': None, 'kernel': dom_name,
+                     'launches_per_step': dom['launches'], 'avg_launch_ms': dom['ms'] / dom['launches'],
+                     'algorithmic_flops_per_step': dom['flops'], 'algorithmic_bytes_per_step': dom['bytes']})
+        conv_flops = sum(f['flops'] for f in fam.values())
+        cnt = res.count.cpu()
+        cand = res.cand.cpu()
+        out = {
+            'metric': 'images/sec @640^2 inference (forward + decode + NMS)', 'value': value, 'unit': 'images/sec',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': f'YOLOv7-s {a.size}x{a.size} batch {a.batch} {a.dtype} inference + GPU decode/NMS '
+                                   f'(BASELINE configs[1]); C={a.classes}, conf {a.conf}, iou {a.iou}',
+                       'global_batch': a.batch * world, 'parallelism': f'replicas x{world}'},
+            'roofline': roof,
+            'network_ms_per_step': net_ms, 'postprocess_ms_per_step': post_ms,
+            'decode_nms_us_per_image': post_ms * 1e3 / a.batch,
+            'network_tflops': conv_flops / (net_ms * 1e-3) / 1e12,
+            'candidates_per_image': float(cand.float().mean()), 'kept_per_image': float(cnt.float().mean()),
+            'kernel_families_ms': {k: round(v['ms'], 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(model, a, margs, x_cpu)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -61,6 +61,10 @@ typedef struct {
 
 int odamd_decode(const odamd_decode_desc* d, float* out, void* stream);
 
+/* deploy.forward (model/layer.py:304) on an already decoded (rows, K) float32 tensor:
+ * sigmoid of channels 4: in place. */
+int odamd_deploy_sigmoid(float* pred, size_t rows, int kdim, void* stream);
+
 /* Backward of odamd_decode with deploy == 0: grad wrt the raw head tensors given grad wrt the
  * decoded tensor and the raw heads (autograd of model/layer.py:279-286).
  * grad_head[i] has the shape of head[i]. */
@@ -96,6 +100,11 @@ int odamd_postprocess(const float* pred, int batch, int rows, int kdim, float co
 int odamd_postprocess_heads(const odamd_decode_desc* d, float conf_thr, float iou_thr, const float* scale_xy,
                             int n_pad, float* out_rows, int* out_idx, int* out_count, int* cand_count,
                             int max_keep, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Stand-alone predict_class._nms (predict.py:82-92): rows are (x_min,y_min,w,h,conf,cls...) and all
+ * of them are candidates; kept rows are returned unchanged, in keep order. */
+int odamd_nms_rows(const float* rows_xywh, int batch, int rows, int kdim, float iou_thr, int n_pad, float* out_rows,
+                   int* out_idx, int* out_count, int max_keep, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Building blocks of the chain, exported for tests and for callers that bring their own
  * candidate set.  boxes: (n) float4 {x_min,y_min,w,h}; bit j of mask word (i, j/64) is set
@@ -145,10 +154,12 @@ int odamd_spp_pool3_forward(const void* x, void* y5, void* y9, void* y13, int ba
                             int x_ld, int y_ld, int dtype, void* stream);
 int odamd_upsample2_forward(const void* x, void* y, int batch, int h, int w, int c, int x_ld, int y_ld,
                             int dtype, void* stream);
-/* Layout converters between NCHW float32 (the module API) and NHWC activations. */
-int odamd_nchw_to_nhwc(const float* x, void* y, int batch, int c, int h, int w, int y_ld, int dtype,
+/* Layout converters between NCHW float32 (the module API) and NHWC activations.  `c` channels
+ * are converted; x_c / y_c is the channel count of the whole NCHW tensor (>= c), so a channel
+ * slice of it can be addressed by offsetting the pointer. */
+int odamd_nchw_to_nhwc(const float* x, void* y, int batch, int c, int h, int w, int x_c, int y_ld, int dtype,
                        void* stream);
-int odamd_nhwc_to_nchw(const void* x, float* y, int batch, int c, int h, int w, int x_ld, int dtype,
+int odamd_nhwc_to_nchw(const void* x, float* y, int batch, int c, int h, int w, int x_ld, int y_c, int dtype,
                        void* stream);
 
 #ifdef __cplusplus

@@ -6,6 +6,11 @@ it is absent: nothing in this package computes on the CPU instead.
 import ctypes as C
 import os
 
+# torch ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be the first one loaded
+# into the process so that this library binds to the SAME runtime instance (streams and device
+# pointers are shared with torch); loading /opt/rocm's copy first leaves torch without a device.
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libodamd.so')
 ABI_VERSION = 1
@@ -38,12 +43,15 @@ SIGNATURES = {
     'odamd_abi_version': (c_int, []),
     'odamd_error_string': (C.c_char_p, [c_int]),
     'odamd_decode': (c_int, [C.POINTER(DecodeDesc), c_void_p, c_void_p]),
+    'odamd_deploy_sigmoid': (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
     'odamd_decode_backward': (c_int, [C.POINTER(DecodeDesc), c_void_p, C.POINTER(c_void_p * 3), c_void_p]),
     'odamd_postprocess_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'odamd_postprocess': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'odamd_postprocess_heads': (c_int, [C.POINTER(DecodeDesc), c_float, c_float, c_void_p, c_int, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'odamd_nms_rows': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                               c_void_p, c_size_t, c_void_p]),
     'odamd_iou_mask': (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p]),
     'odamd_conv_forward': (c_int, [C.POINTER(ConvDesc), c_void_p]),
     'odamd_conv_first_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -52,8 +60,8 @@ SIGNATURES = {
     'odamd_spp_pool3_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_int, c_void_p]),
     'odamd_upsample2_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    'odamd_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    'odamd_nhwc_to_nchw': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'odamd_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'odamd_nhwc_to_nchw': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 MISSING = []

@@ -62,6 +62,12 @@ __global__ void __launch_bounds__(256) decode_kernel(DecodeGeom g, float* __rest
     }
 }
 
+// deploy.forward on an already decoded tensor: sigmoid of channels 4: in place.
+__global__ void __launch_bounds__(256) deploy_sigmoid_kernel(float* __restrict__ pred, size_t n, int kdim) {
+    for (size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x; f < n; f += (size_t)gridDim.x * blockDim.x)
+        if ((int)(f % kdim) >= 4) pred[f] = sigmoid_f32(pred[f]);
+}
+
 // d raw = d out * d(decode)/d raw.  Channels >= 4 pass through (deploy == 0 in training).
 __global__ void __launch_bounds__(256) decode_bwd_kernel(DecodeGeom g, const float* __restrict__ gout,
                                                          float* gh0, float* gh1, float* gh2) {
@@ -104,7 +110,8 @@ __device__ __forceinline__ u64 make_key(float score, int row) {
 constexpr int FILTER_THREADS = 256;
 
 // SRC == 0: `rows` is the deployed (B,R,K) tensor.  SRC == 1: rows come from the raw heads and
-// are decoded + sigmoided while they sit in LDS.
+// are decoded + sigmoided while they sit in LDS.  SRC == 2: rows are already (x_min,y_min,w,h,..)
+// and every row is a candidate (the stand-alone _nms of predict.py:82-92).
 // Each workgroup stages `rows_stage` whole rows in LDS with coalesced loads (row stride padded
 // to an odd number of words so the per-row walk below is bank-conflict free), then one lane
 // per row evaluates predict.py:68-70,83.
@@ -119,7 +126,7 @@ filter_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdim, 
     if (nrow <= 0) return;
     const int ldk = kdim | 1;
     // stage rows [row0, row0+nrow)
-    if (SRC == 0) {
+    if (SRC != 1) {
         const float* src = pred + ((size_t)b * rows + row0) * kdim;
         for (int f = threadIdx.x; f < nrow * kdim; f += FILTER_THREADS) {
             const int r = f / kdim, k = f - r * kdim;
@@ -145,10 +152,10 @@ filter_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdim, 
         if (r < nrow) {
             const float* p = lds + r * ldk;
             const float bw = p[2], bh = p[3];
-            const float xmin = p[0] - bw / 2.0f;
-            const float ymin = p[1] - bh / 2.0f;
+            const float xmin = SRC == 2 ? p[0] : p[0] - bw / 2.0f;
+            const float ymin = SRC == 2 ? p[1] : p[1] - bh / 2.0f;
             const float conf = p[4];
-            pass = (conf > conf_thr) && (xmin > 0.0f) && (ymin > 0.0f);
+            pass = SRC == 2 || ((conf > conf_thr) && (xmin > 0.0f) && (ymin > 0.0f));
             if (pass) {
                 float m = p[5];
                 for (int k = 6; k < kdim; ++k) m = fmaxf(m, p[k]);
@@ -373,7 +380,7 @@ emit_rows_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdi
         float val = 0.f;
         for (int kk = k0; kk < k1; ++kk) {
             float x;
-            if (SRC == 0) {
+            if (SRC != 1) {
                 x = pred[((size_t)b * rows + row) * kdim + kk];
             } else {
                 const int s = row >= g.rows_before[2] ? 2 : (row >= g.rows_before[1] ? 1 : 0);
@@ -385,7 +392,9 @@ emit_rows_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdi
             }
             if (k < 4) v[kk] = x; else val = x;
         }
-        if (k < 4) {
+        if (SRC == 2) {
+            if (k < 4) val = v[k];
+        } else if (k < 4) {
             // x_min = cx - w/2 ; cx' = x_min + w/2 ; scaled.  Same roundings as the reference.
             const float half = v[2 + (k & 1)] / 2.0f;
             if (k < 2) val = ((v[k] - half) + half) * (k == 0 ? xs : ys);
@@ -558,6 +567,15 @@ int odamd_decode_backward(const odamd_decode_desc* d, const float* grad_out, flo
     return (int)hipGetLastError();
 }
 
+int odamd_deploy_sigmoid(float* pred, size_t rows, int kdim, void* stream) {
+    if (!pred || rows < 1 || kdim < 5) return ODAMD_E_ARG;
+    const size_t n = rows * (size_t)kdim;
+    size_t gx = (n + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    deploy_sigmoid_kernel<<<(int)gx, 256, 0, (hipStream_t)stream>>>(pred, n, kdim);
+    return (int)hipGetLastError();
+}
+
 size_t odamd_postprocess_workspace_bytes(int batch, int rows, int kdim, int n_pad) {
     (void)kdim;
     if (batch < 1 || rows < 1) return 0;
@@ -584,6 +602,14 @@ int odamd_postprocess_heads(const odamd_decode_desc* d, float conf_thr, float io
     return postprocess_impl<1>(nullptr, g, d->batch, g.rows, d->kdim, conf_thr, iou_thr, scale_xy, n_pad, out_rows,
                                out_idx, out_count, cand_count, max_keep, workspace, workspace_bytes,
                                (hipStream_t)stream);
+}
+
+int odamd_nms_rows(const float* rows_xywh, int batch, int rows, int kdim, float iou_thr, int n_pad, float* out_rows,
+                   int* out_idx, int* out_count, int max_keep, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!rows_xywh) return ODAMD_E_ARG;
+    DecodeGeom g = {};
+    return postprocess_impl<2>(rows_xywh, g, batch, rows, kdim, 0.0f, iou_thr, nullptr, n_pad, out_rows, out_idx,
+                               out_count, nullptr, max_keep, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int odamd_iou_mask(const float* boxes_xywh, int n, float iou_thr, uint64_t* mask, void* stream) {

@@ -1,0 +1,385 @@
+"""Static execution plans for the YOLOv7 blocks on libodamd.so.
+
+A module tree (model/layer.py, model/yolov7.py mirrors) is lowered ONCE per (input shape,
+compute dtype) into a flat list of kernel launches over pre-allocated NHWC buffers:
+
+* activations are NHWC, bf16 or f32; every `concat` of the reference (model/layer.py:25-27)
+  becomes producers writing at channel offsets of one buffer, so no concat kernel exists;
+* BatchNorm (eval) is folded into a per-channel (scale, shift) pair applied with SiLU in the
+  convolution epilogue (model/layer.py:12-16);
+* MaxPool2d(2,2) in front of a 1x1 conv (mp, model/layer.py:140-141) is applied while the
+  convolution stages its input;
+* the three heads store float32 NCHW, which the reference's raw reshape (model/layer.py:235)
+  reinterprets as (B, A, H, W, K); decode (+ deploy sigmoid) reads that layout directly.
+
+The plan only enqueues work on torch's current HIP stream, so a whole forward can be captured
+in a HIP graph.  There is no fallback: every op is a call into the C ABI.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+F32, BF16 = 0, 1
+_TORCH_DT = {0: torch.float32, 1: torch.bfloat16}
+CH_ALIGN = 16            # channel granule of every buffer slice (one bf16 MFMA k-step)
+
+_compute_dtype = None    # None: follow the parameters' dtype
+
+
+def set_compute_dtype(name):
+    """Force the arithmetic type of all plans: 'bf16', 'f32' or None (follow parameter dtype:
+    float32 parameters -> f32, half/bfloat16 parameters -> bf16)."""
+    global _compute_dtype
+    _compute_dtype = {None: None, 'bf16': BF16, 'f32': F32, 'fp32': F32}[name]
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Act:
+    """Symbolic activation: channels [c0, c0+cphys) of NHWC buffer `buf`.
+
+    `segments` lists (physical offset from c0, logical channel count) runs; gaps between runs
+    are zero padding that keeps every run 16-channel aligned (pruned, irregular widths).
+    """
+
+    def __init__(self, buf, c0, segments, h, w):
+        self.buf, self.c0, self.segments, self.h, self.w = buf, c0, segments, h, w
+
+    @property
+    def c(self):
+        return sum(n for _, n in self.segments)
+
+    @property
+    def cphys(self):
+        off, n = self.segments[-1]
+        return _round_up(off + n, CH_ALIGN)
+
+
+class PlanBuilder:
+    def __init__(self, batch, dtype, device):
+        self.batch, self.dtype, self.device = batch, dtype, device
+        self.buffers = []      # (cphys, h, w)
+        self.ops = []          # dicts, resolved to launches by Plan
+        self.convs = []        # ops that own packed weights
+
+    # ---- buffers -----------------------------------------------------------------------
+    def buffer(self, widths, h, w):
+        """New NHWC buffer holding a concat of slices with the given logical widths.
+        Returns (whole Act, [slice Acts])."""
+        segs, off = [], 0
+        for n in widths:
+            segs.append((off, n))
+            off += _round_up(n, CH_ALIGN)
+        self.buffers.append((off, h, w))
+        bid = len(self.buffers) - 1
+        whole = Act(bid, 0, segs, h, w)
+        return whole, [Act(bid, o, [(0, n)], h, w) for o, n in segs]
+
+    def single(self, c, h, w):
+        return self.buffer([c], h, w)[0]
+
+    # ---- ops ---------------------------------------------------------------------------
+    def conv(self, mod, x, out=None, pool=False):
+        """cbs block (model/layer.py:4-16); pool=True applies MaxPool2d(2,2) to x on load."""
+        k, s = mod.conv.kernel_size[0], mod.conv.stride[0]
+        h, w = (x.h // 2, x.w // 2) if pool else (x.h, x.w)
+        ho, wo = (h + 2 * ((k - 1) // 2) - k) // s + 1, (w + 2 * ((k - 1) // 2) - k) // s + 1
+        cout = mod.conv.out_channels
+        if out is None:
+            out = self.single(cout, ho, wo)
+        assert out.c == cout and out.h == ho and out.w == wo and x.c == mod.conv.in_channels
+        op = dict(kind='conv', mod=mod, x=x, y=out, k=k, s=s, pool=pool, act=1)
+        self.ops.append(op)
+        self.convs.append(op)
+        return out
+
+    def first(self, mod, image_hw):
+        """cbs0 straight from the float32 NCHW image (3 input channels)."""
+        h, w = image_hw
+        out = self.single(mod.conv.out_channels, h, w)
+        op = dict(kind='first', mod=mod, y=out)
+        self.ops.append(op)
+        self.convs.append(op)
+        return out
+
+    def head(self, mod, x):
+        """head.output: 1x1 conv + bias, float32 NCHW (model/layer.py:232-235)."""
+        op = dict(kind='head', mod=mod, x=x, k=1, s=1, pool=False, act=0, cout=mod.output.out_channels)
+        self.ops.append(op)
+        self.convs.append(op)
+        return op
+
+    def maxpool2(self, x, out=None):
+        out = out or self.single(x.c, x.h // 2, x.w // 2)
+        self.ops.append(dict(kind='maxpool2', x=x, y=out))
+        return out
+
+    def spp(self, x, outs):
+        self.ops.append(dict(kind='spp', x=x, ys=outs))
+
+    def upsample2(self, x, out=None):
+        out = out or self.single(x.c, 2 * x.h, 2 * x.w)
+        self.ops.append(dict(kind='upsample2', x=x, y=out))
+        return out
+
+    def copy(self, x, out):
+        """Plain channel-slice copy (only used by a stand-alone `concat` module)."""
+        self.ops.append(dict(kind='copy', x=x, y=out))
+        return out
+
+    def from_nchw(self, c, h, w):
+        out = self.single(c, h, w)
+        self.ops.append(dict(kind='from_nchw', y=out))
+        return out
+
+    def to_nchw(self, x):
+        self.ops.append(dict(kind='to_nchw', x=x))
+
+
+def _fold_bn(bn):
+    """Eval-mode BatchNorm as y*scale + shift (model/layer.py:9,14)."""
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+    return scale, shift
+
+
+def _pack_weight(w, x_act, dtype):
+    """(cout, cin, k, k) -> [cout][ky][kx][cin_phys] in the compute dtype, zero columns in gaps."""
+    cout, cin, k, _ = w.shape
+    wt = w.detach().float().permute(0, 2, 3, 1)
+    if x_act is None or (len(x_act.segments) == 1 and x_act.cphys == cin):
+        packed = wt
+    else:
+        packed = torch.zeros((cout, k, k, x_act.cphys), dtype=torch.float32, device=w.device)
+        src = 0
+        for off, n in x_act.segments:
+            packed[..., off:off + n] = wt[..., src:src + n]
+            src += n
+    return packed.to(_TORCH_DT[dtype]).contiguous()
+
+
+class Plan:
+    """Lowered module: buffers allocated, descriptors built, ready to run."""
+
+    def __init__(self, builder, finish=None):
+        self.b = builder
+        dt = _TORCH_DT[builder.dtype]
+        self.bufs = [torch.zeros((builder.batch, h, w, c), dtype=dt, device=builder.device)
+                     for c, h, w in builder.buffers]
+        self.es = 2 if builder.dtype == BF16 else 4
+        self.launches = []
+        self.meta = {}          # launch index -> {kernel, flops, bytes, shape} (algorithmic work, for profiling)
+        self.keep = []          # tensors the descriptors point into
+        self.weight_version = None
+        self.outputs = {}
+        self.finish = finish
+        self._build()
+
+    # ---- addressing ----------------------------------------------------------------------
+    def _ptr(self, act):
+        t = self.bufs[act.buf]
+        return t.data_ptr() + act.c0 * self.es
+
+    def _ld(self, act):
+        return self.bufs[act.buf].shape[3]
+
+    # ---- weights ---------------------------------------------------------------------------
+    def _versions(self):
+        v = 0
+        for op in self.b.convs:
+            m = op['mod']
+            if op['kind'] == 'head':
+                v += m.output.weight._version + m.output.bias._version
+            else:
+                v += m.conv.weight._version + m.bn.weight._version + m.bn.bias._version
+                v += m.bn.running_mean._version + m.bn.running_var._version
+        return v
+
+    def refresh_weights(self):
+        """(Re)pack weights and folded BN constants into the buffers the descriptors point at."""
+        ver = self._versions()
+        if ver == self.weight_version:
+            return
+        with torch.no_grad():
+            for op in self.b.convs:
+                m = op['mod']
+                if op['kind'] == 'head':
+                    w = _pack_weight(m.output.weight, op['x'], self.b.dtype)
+                    op['w'].copy_(w.view(-1))
+                    op['shift'].copy_(m.output.bias.detach().float())
+                elif op['kind'] == 'first':
+                    op['w'].copy_(m.conv.weight.detach().float().permute(0, 2, 3, 1).reshape(-1))
+                    sc, sh = _fold_bn(m.bn)
+                    op['scale'].copy_(sc)
+                    op['shift'].copy_(sh)
+                else:
+                    w = _pack_weight(m.conv.weight, op['x'], self.b.dtype)
+                    op['w'].copy_(w.view(-1))
+                    sc, sh = _fold_bn(m.bn)
+                    op['scale'].copy_(sc)
+                    op['shift'].copy_(sh)
+        self.weight_version = ver
+
+    # ---- lowering ---------------------------------------------------------------------------
+    def _build(self):
+        b, dev, dt = self.b, self.b.device, _TORCH_DT[self.b.dtype]
+        B = b.batch
+        for op in b.ops:
+            kind = op['kind']
+            if kind in ('conv', 'head'):
+                m, x = op['mod'], op['x']
+                conv = m.output if kind == 'head' else m.conv
+                cout, k = conv.out_channels, op['k']
+                op['w'] = torch.empty(cout * k * k * x.cphys, dtype=dt, device=dev)
+                op['shift'] = torch.empty(cout, dtype=torch.float32, device=dev)
+                op['scale'] = None if kind == 'head' else torch.empty(cout, dtype=torch.float32, device=dev)
+                d = _lib.ConvDesc()
+                d.x, d.w = self._ptr(x), op['w'].data_ptr()
+                d.scale = op['scale'].data_ptr() if op['scale'] is not None else None
+                d.shift = op['shift'].data_ptr()
+                d.batch, d.h, d.w_in, d.cin, d.cout = B, x.h, x.w, x.cphys, cout
+                d.x_ld, d.ksize, d.stride, d.act = self._ld(x), k, op['s'], op['act']
+                d.dtype, d.in_pool2 = b.dtype, int(op['pool'])
+                if kind == 'head':
+                    out = torch.empty((B, cout, x.h, x.w), dtype=torch.float32, device=dev)
+                    op['out'] = out
+                    d.y, d.y_ld, d.out_nchw_f32 = out.data_ptr(), 0, 1
+                else:
+                    d.y, d.y_ld, d.out_nchw_f32 = self._ptr(op['y']), self._ld(op['y']), 0
+                self.keep.append(d)
+                self.launches.append((lib.odamd_conv_forward, [C.byref(d)], 'conv', None))
+                ho = (d.h // (2 if op['pool'] else 1) + 2 * ((k - 1) // 2) - k) // op['s'] + 1
+                wo = (d.w_in // (2 if op['pool'] else 1) + 2 * ((k - 1) // 2) - k) // op['s'] + 1
+                cin = conv.in_channels
+                self.meta[len(self.launches) - 1] = dict(
+                    kernel='conv%dx%d_s%d_%s' % (k, k, op['s'], 'c32' if cout <= 32 else 'c64' if cout <= 64 else 'c128'),
+                    flops=2.0 * B * ho * wo * cout * k * k * cin,
+                    bytes=float(B * x.h * x.w * cin * self.es + B * ho * wo * cout * (4 if kind == 'head' else self.es)
+                                + cout * k * k * cin * self.es),
+                    shape='%dx%d %d->%d' % (x.h, x.w, cin, cout))
+            elif kind == 'first':
+                m, y = op['mod'], op['y']
+                cout = m.conv.out_channels
+                op['w'] = torch.empty(cout * 27, dtype=torch.float32, device=dev)
+                op['scale'] = torch.empty(cout, dtype=torch.float32, device=dev)
+                op['shift'] = torch.empty(cout, dtype=torch.float32, device=dev)
+                self.launches.append((lib.odamd_conv_first_forward,
+                                      [0, op['w'].data_ptr(), op['scale'].data_ptr(), op['shift'].data_ptr(),
+                                       self._ptr(y), B, y.h, y.w, cout, self._ld(y), b.dtype], 'first', 0))
+            elif kind == 'maxpool2':
+                x, y = op['x'], op['y']
+                self.launches.append((lib.odamd_maxpool2_forward,
+                                      [self._ptr(x), self._ptr(y), B, x.h, x.w, x.cphys, self._ld(x), self._ld(y),
+                                       b.dtype], 'maxpool2', None))
+            elif kind == 'spp':
+                x, ys = op['x'], op['ys']
+                self.launches.append((lib.odamd_spp_pool3_forward,
+                                      [self._ptr(x), self._ptr(ys[0]), self._ptr(ys[1]), self._ptr(ys[2]), B, x.h, x.w,
+                                       x.cphys, self._ld(x), self._ld(ys[0]), b.dtype], 'spp', None))
+            elif kind == 'upsample2':
+                x, y = op['x'], op['y']
+                self.launches.append((lib.odamd_upsample2_forward,
+                                      [self._ptr(x), self._ptr(y), B, x.h, x.w, x.cphys, self._ld(x), self._ld(y),
+                                       b.dtype], 'upsample2', None))
+            elif kind == 'copy':
+                x, y = op['x'], op['y']
+                self.launches.append((None, [x, y], 'copy', None))
+            elif kind == 'from_nchw':
+                y = op['y']
+                self.launches.append((lib.odamd_nchw_to_nhwc,
+                                      [0, self._ptr(y), B, y.c, y.h, y.w, y.c, self._ld(y), b.dtype], 'from_nchw', 0))
+            elif kind == 'to_nchw':
+                x = op['x']
+                out = torch.empty((B, x.c, x.h, x.w), dtype=torch.float32, device=dev)
+                self.outputs['nchw'] = out
+                dst = 0
+                for off, n in x.segments:   # one launch per concat slice (gaps are padding)
+                    self.launches.append((lib.odamd_nhwc_to_nchw,
+                                          [self._ptr(x) + off * self.es, out.data_ptr() + dst * x.h * x.w * 4, B, n,
+                                           x.h, x.w, self._ld(x), x.c, b.dtype], 'to_nchw', None))
+                    dst += n
+            else:
+                raise AssertionError(kind)
+
+    def run(self, image):
+        """Enqueue the whole plan on the current stream. `image`: contiguous float32 NCHW."""
+        self.refresh_weights()
+        st = _stream()
+        img = image.data_ptr()
+        for fn, args, name, image_slot in self.launches:
+            if name == 'copy':
+                x, y = args
+                self.bufs[y.buf][..., y.c0:y.c0 + x.cphys].copy_(self.bufs[x.buf][..., x.c0:x.c0 + x.cphys])
+                continue
+            if image_slot is not None:
+                args[image_slot] = img
+            rc = fn(*args, st)
+            if rc:
+                check(rc, name)
+        return self.finish(self, image) if self.finish else self.outputs.get('nchw')
+
+    def profile(self, image, repeats=3):
+        """Per-launch device time in ms (median of `repeats`), HIP events on the launch stream."""
+        self.refresh_weights()
+        st = _stream()
+        img = image.data_ptr()
+        times = [[] for _ in self.launches]
+        for _ in range(repeats):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(self.launches) + 1)]
+            evs[0].record()
+            for i, (fn, args, name, image_slot) in enumerate(self.launches):
+                if name != 'copy':
+                    if image_slot is not None:
+                        args[image_slot] = img
+                    check(fn(*args, st), name)
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+            for i in range(len(self.launches)):
+                times[i].append(evs[i].elapsed_time(evs[i + 1]))
+        out = []
+        for i, (fn, args, name, _) in enumerate(self.launches):
+            m = dict(self.meta.get(i, {'kernel': name, 'flops': 0.0, 'bytes': 0.0, 'shape': ''}))
+            m['ms'] = sorted(times[i])[len(times[i]) // 2]
+            out.append(m)
+        return out
+
+
+def compute_dtype_for(module):
+    if _compute_dtype is not None:
+        return _compute_dtype
+    for p in module.parameters():
+        return F32 if p.dtype == torch.float32 else BF16
+    return F32
+
+
+_plans = {}
+
+
+def run_module(module, x, emit=None):
+    """Generic forward of one block: NCHW tensor in, NCHW tensor out, through a cached plan."""
+    if not x.is_cuda:
+        raise RuntimeError('objectdetection_amd blocks run on the GPU only (no CPU fallback)')
+    if module.training:
+        raise RuntimeError('stand-alone blocks run in eval mode; training goes through yolov7.forward')
+    dtype = compute_dtype_for(module)
+    key = (id(module), tuple(x.shape), dtype, x.device.index)
+    plan = _plans.get(key)
+    if plan is None:
+        b, c, h, w = x.shape
+        pb = PlanBuilder(b, dtype, x.device)
+        xin = pb.from_nchw(c, h, w)
+        out = (emit or module._emit)(pb, xin)
+        pb.to_nchw(out)
+        plan = Plan(pb)
+        _plans[key] = plan
+    y = plan.run(x.detach().float().contiguous())
+    return y.clone() if x.dtype == torch.float32 else y.to(x.dtype)

@@ -47,6 +47,15 @@ def decode(heads, input_size, anchor, deploy=False):
     return out
 
 
+def deploy_sigmoid_(pred):
+    """In-place sigmoid of channels 4: of a contiguous float32 (..., K) CUDA tensor (model/layer.py:304)."""
+    if pred.dtype != torch.float32 or not pred.is_contiguous() or not pred.is_cuda:
+        raise ValueError('pred must be a contiguous float32 CUDA tensor')
+    k = pred.shape[-1]
+    check(lib.odamd_deploy_sigmoid(_ptr(pred), pred.numel() // k, k, _stream()), 'deploy_sigmoid')
+    return pred
+
+
 def decode_backward(heads, input_size, anchor, grad_out):
     d = decode_desc(heads, input_size, anchor, False)
     grads = [torch.empty_like(h) for h in heads]
@@ -123,3 +132,17 @@ def postprocess_heads(heads, input_size, anchor, confidence_threshold, iou_thres
                                       n_pad, _ptr(rows), _ptr(idx), _ptr(cnt), _ptr(cand), max_keep, _ptr(ws),
                                       ws.numel(), _stream()), 'postprocess_heads')
     return PostResult(rows, idx, cnt, cand)
+
+
+def nms_rows(rows, iou_threshold, max_keep=None, n_pad=0):
+    """Stand-alone predict.py:82-92 on (B,N,K) or (N,K) float32 CUDA rows (x_min,y_min,w,h,conf,cls...)."""
+    if rows.dim() == 2:
+        rows = rows.unsqueeze(0)
+    rows = rows.contiguous()
+    b, n, k = rows.shape
+    max_keep = max_keep or n
+    ws = _workspace(lib.odamd_postprocess_workspace_bytes(b, n, k, n_pad), rows.device)
+    out, idx, cnt, cand = _outputs(b, k, max_keep, rows.device)
+    check(lib.odamd_nms_rows(_ptr(rows), b, n, k, float(iou_threshold), n_pad, _ptr(out), _ptr(idx), _ptr(cnt),
+                             max_keep, _ptr(ws), ws.numel(), _stream()), 'nms_rows')
+    return PostResult(out, idx, cnt, cnt)

@@ -1,0 +1,53 @@
+"""The C-ABI library must load on a machine without a GPU and export every declared symbol."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'odamd.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(odamd_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from objectdetection_amd import _lib
+    names = _declared()
+    assert len(names) >= 15
+    assert _lib.MISSING == []
+    for n in names:
+        assert hasattr(_lib.lib, n), n
+        assert n in _lib.SIGNATURES, f'{n} has no ctypes signature'
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_error_strings_and_version():
+    from objectdetection_amd import _lib
+    assert _lib.lib.odamd_abi_version() == _lib.ABI_VERSION
+    assert b'workspace' in _lib.lib.odamd_error_string(-3)
+    assert _lib.lib.odamd_postprocess_workspace_bytes(2, 25200, 85, 0) > 0
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected before any HIP call, so this runs on a CPU-only box."""
+    import ctypes as C
+    from objectdetection_amd import _lib
+    d = _lib.ConvDesc()
+    assert _lib.lib.odamd_conv_forward(C.byref(d), None) == -1
+    assert _lib.lib.odamd_postprocess(None, 1, 10, 6, 0.5, 0.5, None, 0, None, None, None, None, 10, None, 0, None) == -1
+    assert _lib.lib.odamd_iou_mask(None, 64, 0.5, None, None) == -1
+
+
+def test_state_dict_names_match_reference_layout():
+    """474 entries for preset s (SURVEY probe of the reference), fixed key examples."""
+    from objectdetection_amd.model.yolov7 import yolov7
+    from oracle import patterns
+    m = yolov7(patterns.default_args(input_size=64, output_class=80))
+    sd = m.state_dict()
+    assert len(sd) == 474
+    for k in ('cbs0.conv.weight', 'cbs0.bn.running_mean', 'elan4.sequential2.0.conv.weight', 'mp5.cbs3.bn.bias',
+              'sppcspc11.cbs11.conv.weight', 'l8_concat.bn.num_batches_tracked', 'elan_h25.cbs7.conv.weight',
+              'head2.output.bias'):
+        assert k in sd, k
+    assert sum(p.numel() for p in m.parameters()) == 7010957
