@@ -20,6 +20,8 @@
 
 namespace {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // 16-byte register carrier
+
 template <int DT> struct Elem;
 template <> struct Elem<ODAMD_DTYPE_BF16> { static constexpr int SIZE = 2; };
 template <> struct Elem<ODAMD_DTYPE_F32> { static constexpr int SIZE = 4; };
@@ -27,7 +29,7 @@ template <> struct Elem<ODAMD_DTYPE_F32> { static constexpr int SIZE = 4; };
 // One k-step: 32 bytes of input channels per pixel (16 bf16 / 8 f32); lane half h holds the
 // 16 bytes at offset 16*h of both operands.
 template <int DT>
-__device__ __forceinline__ void mma_step(f32x16_t& acc, const uint4& a, const uint4& b) {
+__device__ __forceinline__ void mma_step(f32x16_t& acc, const u32x4& a, const u32x4& b) {
     if constexpr (DT == ODAMD_DTYPE_BF16) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
                                                       acc, 0, 0, 0);
@@ -38,18 +40,26 @@ __device__ __forceinline__ void mma_step(f32x16_t& acc, const uint4& a, const ui
     }
 }
 
-__device__ __forceinline__ uint4 vmax16(const uint4& p, const uint4& q, int dt) {
-    uint4 r;
+__device__ __forceinline__ u32x4 vmax16(const u32x4& p, const u32x4& q, int dt) {
+    u32x4 r;
     if (dt == ODAMD_DTYPE_F32) {
-        const float* a = (const float*)&p; const float* b = (const float*)&q; float* o = (float*)&r;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = fmaxf(a[i], b[i]);
+        for (int i = 0; i < 4; ++i) r[i] = __float_as_uint(fmaxf(__uint_as_float(p[i]), __uint_as_float(q[i])));
     } else {
-        const uint16_t* a = (const uint16_t*)&p; const uint16_t* b = (const uint16_t*)&q; uint16_t* o = (uint16_t*)&r;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32(a[i]) >= bf16_to_f32(b[i]) ? a[i] : b[i];
+        for (int i = 0; i < 4; ++i) {   // two bf16 per word; compare as floats, keep the bits
+            const uint32_t a = p[i], b = q[i];
+            const uint32_t lo = __uint_as_float(a << 16) >= __uint_as_float(b << 16) ? (a & 0xFFFFu) : (b & 0xFFFFu);
+            const uint32_t hi = __uint_as_float(a & 0xFFFF0000u) >= __uint_as_float(b & 0xFFFF0000u) ? (a & 0xFFFF0000u)
+                                                                                                   : (b & 0xFFFF0000u);
+            r[i] = lo | hi;
+        }
     }
     return r;
+}
+__device__ __forceinline__ uint4 vmax16(const uint4& p, const uint4& q, int dt) {
+    const u32x4 r = vmax16(u32x4{p.x, p.y, p.z, p.w}, u32x4{q.x, q.y, q.z, q.w}, dt);
+    return make_uint4(r[0], r[1], r[2], r[3]);
 }
 
 template <int DT>
@@ -75,9 +85,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
+// Upper bound of staged input pixels per workgroup (the host tile chooser enforces it), so
+// that the per-thread prefetch registers have a compile-time size.
+__host__ __device__ constexpr int max_in_pix(int ks, int st, int pg) {
+    return ks == 1 ? 32 * pg : (st == 1 ? (pg == 8 ? 400 : 232) : (pg == 4 ? 608 : 1200));
+}
+
 // CG: 32-channel groups per workgroup, PG: 32-pixel groups per workgroup,
 // WP x WC = 4 waves over (pixel groups, channel groups), CKB: bytes of input channels per chunk.
-template <int DT, int KS, int ST, int CG, int PG, int WP, int WC, int CKB>
+//
+// Pipeline per input-channel chunk: the global loads of chunk c+1 are issued into registers
+// before the matrix work of chunk c starts and are written to LDS after it (one LDS buffer,
+// two barriers per chunk); the address arithmetic of every staged 16-byte piece is done once
+// before the loop.  POOL (2x2 max pool on load) stages synchronously instead.
+// Epilogue: each wave transposes its 32-pixel x (32*CGW)-channel results through a private LDS
+// slice so that global stores are 16 bytes per lane and whole 64..256-byte runs per pixel.
+template <int DT, int KS, int ST, int CG, int PG, int WP, int WC, int CKB, bool POOL>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
     constexpr int ES = Elem<DT>::SIZE;
     constexpr int TAPS = KS * KS;
@@ -86,6 +109,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
     constexpr int PGW = PG / WP, CGW = CG / WC;
     constexpr int PARTS = CKB / 16;
     constexpr int PAD = (KS - 1) / 2;
+    constexpr int NP_IN = (max_in_pix(KS, ST, PG) * PARTS + 255) / 256;
+    constexpr int NP_W = (32 * CG * TAPS * PARTS + 255) / 256;
     static_assert(WP * WC == 4, "four waves");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* lds_in = lds;
@@ -102,19 +127,44 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
     const int r = lane & 31, h = lane >> 5;
     const int wp = wave / WC, wc = wave % WC;
 
-    // per-lane LDS offsets of this wave's pixel groups / channel groups
+    // ---- per-lane LDS offsets of this wave's pixel groups / channel groups ----------------------
     int b_off[PGW], a_off[CGW];
-    int q_y[PGW], q_x[PGW];
+    int opix[PGW];   // output pixel index of (group i, lane r) within the image, -1 when outside
 #pragma unroll
     for (int i = 0; i < PGW; ++i) {
         const int q = (wp * PGW + i) * 32 + r;
         int ty = q / p.TW, tx = q - ty * p.TW;
-        q_y[i] = ty; q_x[i] = tx;
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        opix[i] = (ty < p.TH && oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
         if (ty >= p.TH) { ty = 0; tx = 0; }
         b_off[i] = ((ty * ST) * p.IW + tx * ST) * PS + 16 * h;
     }
 #pragma unroll
     for (int i = 0; i < CGW; ++i) a_off[i] = ((wc * CGW + i) * 32 + r) * WRS + 16 * h;
+
+    // ---- staging descriptors: global byte offset (or -1 = zero fill) and LDS offset per piece ------
+    const int n_in = p.IH * p.IW * PARTS;
+    const int iy0 = oy0 * ST - PAD, ix0 = ox0 * ST - PAD;
+    int in_g[NP_IN], w_g[NP_W];
+#pragma unroll
+    for (int j = 0; j < NP_IN; ++j) {
+        const int i = tid + j * 256;
+        const int pix = i / PARTS, part = i - pix * PARTS;
+        const int iy = pix / p.IW, ix = pix - iy * p.IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        const bool inside = i < n_in && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        if (POOL) in_g[j] = inside ? ((2 * gy) * p.Wr + 2 * gx) * p.x_ld * ES + part * 16 : -1;
+        else in_g[j] = inside ? (gy * p.W + gx) * p.x_ld * ES + part * 16 : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < NP_W; ++j) {
+        const int i = tid + j * 256;
+        const int row = i / (TAPS * PARTS), rem = i - row * (TAPS * PARTS);
+        const int tap = rem / PARTS, part = rem - tap * PARTS;
+        const int co = co0 + row;
+        w_g[j] = (row < 32 * CG && co < p.Cout) ? ((co * TAPS + tap) * p.Cin) * ES + part * 16 : -1;
+    }
+    const char* xb = p.x + (size_t)b * (POOL ? (size_t)p.Hr * p.Wr : (size_t)p.H * p.W) * p.x_ld * ES;
 
     f32x16_t acc[PGW][CGW];
 #pragma unroll
@@ -124,53 +174,56 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    const int n_in = p.IH * p.IW * PARTS;
-    const int n_w = 32 * CG * TAPS * PARTS;
-    const int iy0 = oy0 * ST - PAD, ix0 = ox0 * ST - PAD;
-    const size_t img = (size_t)b * p.H * p.W;      // pixels before this image (pooled grid if pool)
-    const uint4 zero = make_uint4(0, 0, 0, 0);
+    const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
+    u32x4 v_in[NP_IN], v_w[NP_W];
+#define ODAMD_FETCH(C0)                                                                                   \
+    {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < NP_IN; ++j) {                                               \
+            if (POOL) {                                                                                   \
+                u32x4 v = zero;                                                                           \
+                if (in_g[j] >= 0) {                                                                       \
+                    const char* s_ = xb + in_g[j] + (C0);                                                 \
+                    const size_t px_ = (size_t)p.x_ld * ES, row_ = (size_t)p.Wr * px_;                    \
+                    v = vmax16(vmax16(*(const u32x4*)s_, *(const u32x4*)(s_ + px_), DT),                  \
+                               vmax16(*(const u32x4*)(s_ + row_), *(const u32x4*)(s_ + row_ + px_), DT), DT); \
+                }                                                                                         \
+                v_in[j] = v;                                                                              \
+            } else {                                                                                      \
+                v_in[j] = in_g[j] >= 0 ? *(const u32x4*)(xb + in_g[j] + (C0)) : zero;                     \
+            }                                                                                             \
+        }                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < NP_W; ++j)                                                  \
+            v_w[j] = w_g[j] >= 0 ? *(const u32x4*)(p.w + w_g[j] + (C0)) : zero;                           \
+    }
+#define ODAMD_COMMIT()                                                                                    \
+    {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < NP_IN; ++j) {                                               \
+            const int i_ = tid + j * 256;                                                                 \
+            if (i_ < n_in) *(u32x4*)(lds_in + (i_ / PARTS) * PS + (i_ % PARTS) * 16) = v_in[j];           \
+        }                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < NP_W; ++j) {                                                \
+            const int i_ = tid + j * 256;                                                                 \
+            if (i_ < 32 * CG * TAPS * PARTS)                                                              \
+                *(u32x4*)(lds_w + (i_ / (TAPS * PARTS)) * WRS + (i_ % (TAPS * PARTS)) * 16) = v_w[j];     \
+        }                                                                                                 \
+    }
 
-    for (int c0 = 0; c0 < p.Cin * ES; c0 += CKB) {  // c0 in bytes
-        // ---- stage the input halo patch -------------------------------------------------------
-        for (int i = tid; i < n_in; i += 256) {
-            const int pix = i / PARTS, part = i - pix * PARTS;
-            const int iy = pix / p.IW, ix = pix - iy * p.IW;
-            const int gy = iy0 + iy, gx = ix0 + ix;
-            uint4 v = zero;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                if (!p.pool) {
-                    v = *(const uint4*)(p.x + ((img + (size_t)gy * p.W + gx) * p.x_ld) * ES + c0 + part * 16);
-                } else {  // 2x2/2 max pool of the raw (2H x 2W) tensor on the fly
-                    const size_t rw = (size_t)p.Wr;
-                    const char* s = p.x + ((((size_t)b * p.Hr + 2 * gy) * rw + 2 * gx) * p.x_ld) * ES + c0 + part * 16;
-                    const size_t px = (size_t)p.x_ld * ES;
-                    v = vmax16(vmax16(*(const uint4*)s, *(const uint4*)(s + px), DT),
-                               vmax16(*(const uint4*)(s + rw * px), *(const uint4*)(s + rw * px + px), DT), DT);
-                }
-            }
-            *(uint4*)(lds_in + pix * PS + part * 16) = v;
-        }
-        // ---- stage the weight slab: rows = output channels, [tap][chunk] -------------------------
-        for (int i = tid; i < n_w; i += 256) {
-            const int row = i / (TAPS * PARTS), rem = i - row * (TAPS * PARTS);
-            const int tap = rem / PARTS, part = rem - tap * PARTS;
-            const int co = co0 + row;
-            uint4 v = zero;
-            if (co < p.Cout) v = *(const uint4*)(p.w + ((size_t)(co * TAPS + tap) * p.Cin) * ES + c0 + part * 16);
-            *(uint4*)(lds_w + row * WRS + tap * CKB + part * 16) = v;
-        }
+    const int cbytes = p.Cin * ES;
+    ODAMD_FETCH(0)
+    for (int c0 = 0; c0 < cbytes; c0 += CKB) {
+        ODAMD_COMMIT()
         __syncthreads();
-        // ---- k*k taps over the staged patch ------------------------------------------------------
+        if (c0 + CKB < cbytes) ODAMD_FETCH(c0 + CKB)  // in flight while the matrix cores work
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int tap_off = ((tap / KS) * p.IW + (tap % KS)) * PS;
 #pragma unroll
             for (int s = 0; s < CKB / 32; ++s) {
-                uint4 a[CGW], bb[PGW];
+                u32x4 a[CGW], bb[PGW];
 #pragma unroll
-                for (int j = 0; j < CGW; ++j) a[j] = *(const uint4*)(lds_w + a_off[j] + tap * CKB + s * 32);
+                for (int j = 0; j < CGW; ++j) a[j] = *(const u32x4*)(lds_w + a_off[j] + tap * CKB + s * 32);
 #pragma unroll
-                for (int i = 0; i < PGW; ++i) bb[i] = *(const uint4*)(lds_in + b_off[i] + tap_off + s * 32);
+                for (int i = 0; i < PGW; ++i) bb[i] = *(const u32x4*)(lds_in + b_off[i] + tap_off + s * 32);
 #pragma unroll
                 for (int i = 0; i < PGW; ++i)
 #pragma unroll
@@ -180,55 +233,97 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds pixel (group i, r) x channels {8g + 4h + e} of each 32-channel group ----
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // lane (r, h) holds, for pixel (group i, r), channels {8g + 4h + e : g, e in 0..3} of group j.
+    const int cw0 = co0 + wc * CGW * 32;     // first channel of this wave
+    if (p.nchw) {   // float32 NCHW: lanes are consecutive pixels, stores coalesce as they are
 #pragma unroll
-    for (int i = 0; i < PGW; ++i) {
-        const int oy = oy0 + q_y[i], ox = ox0 + q_x[i];
-        if (q_y[i] >= p.TH || oy >= p.Ho || ox >= p.Wo) continue;
-        const size_t opix = ((size_t)b * p.Ho + oy) * p.Wo + ox;
+        for (int j = 0; j < CGW; ++j)
 #pragma unroll
-        for (int j = 0; j < CGW; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = co0 + (wc * CGW + j) * 32 + 8 * g + 4 * h;
-                float v[4];
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int c = co + e;
-                    float t = acc[i][j][4 * g + e];
-                    if (c < p.Cout) {
-                        if (p.scale) t *= p.scale[c];
-                        if (p.shift) t += p.shift[c];
+                    const int c = cw0 + j * 32 + 8 * g + 4 * h + e;
+                    if (c >= p.Cout) continue;
+                    const float scv = p.scale ? p.scale[c] : 1.0f, shv = p.shift ? p.shift[c] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < PGW; ++i) {
+                        float t = acc[i][j][4 * g + e] * scv + shv;
+                        if (p.act) t = silu<DT>(t);
+                        if (opix[i] >= 0) ((float*)p.y)[((size_t)b * p.Cout + c) * p.Ho * p.Wo + opix[i]] = t;
                     }
-                    v[e] = p.act ? silu<DT>(t) : t;
                 }
-                if (p.nchw) {
+        return;
+    }
+    // NHWC: the wave parks its raw f32 accumulators in a private LDS slice [32 pixels][32*CGW
+    // channels]; reading it back, every lane owns CPL fixed consecutive channels (so it fetches
+    // their scale/shift once), applies affine + SiLU and stores 16 bytes; LPR lanes cover one
+    // pixel's 64..256-byte channel run.
+    constexpr int CPL = 16 / ES;             // channels per lane in the read-back (16-byte store)
+    constexpr int NCH = CGW * 32;            // channels per pixel held by this wave
+    constexpr int RS = NCH * 4 + 16;         // padded LDS row (f32)
+    constexpr int LPR = NCH / CPL;           // lanes per pixel row
+    constexpr int RPP = 64 / LPR;            // pixel rows per pass
+    char* stage = lds + wave * (32 * RS);
+    const int part = lane % LPR;
+    const int c_lane = cw0 + part * CPL;
+    float scl[CPL], shf[CPL];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (co + e < p.Cout)
-                            ((float*)p.y)[(((size_t)b * p.Cout + co + e) * p.Ho + oy) * p.Wo + ox] = v[e];
-                } else if (co + 3 < p.Cout) {
-                    char* dst = p.y + (opix * p.y_ld + co) * ES;
-                    if constexpr (DT == ODAMD_DTYPE_F32) {
-                        *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-                        uint2 pk;
-                        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                        *(uint2*)dst = pk;
-                    }
+    for (int e = 0; e < CPL; ++e) {
+        scl[e] = (p.scale && c_lane + e < p.Cout) ? p.scale[c_lane + e] : 1.0f;
+        shf[e] = (p.shift && c_lane + e < p.Cout) ? p.shift[c_lane + e] : 0.0f;
+    }
+    const size_t ybase = (size_t)b * p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < PGW; ++i) {
+#pragma unroll
+        for (int j = 0; j < CGW; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(stage + r * RS + (j * 32 + 8 * g + 4 * h) * 4) =
+                    make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int row = ps * RPP + lane / LPR;
+            const int op = __shfl(opix[i], row);
+            float v[CPL];
+#pragma unroll
+            for (int e = 0; e < CPL; e += 4) {
+                const float4 t = *(const float4*)(stage + row * RS + (part * CPL + e) * 4);
+                v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+            }
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+                const float t = v[e] * scl[e] + shf[e];
+                v[e] = p.act ? silu<DT>(t) : t;
+            }
+            if (op >= 0 && c_lane < p.Cout) {
+                char* dst = p.y + ((ybase + op) * p.y_ld + c_lane) * ES;
+                u32x4 pk;
+                if constexpr (DT == ODAMD_DTYPE_F32) {
+                    pk = u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
                 } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (co + e < p.Cout) {
-                            if constexpr (DT == ODAMD_DTYPE_F32) ((float*)p.y)[opix * p.y_ld + co + e] = v[e];
-                            else ((uint16_t*)p.y)[opix * p.y_ld + co + e] = f32_to_bf16(v[e]);
-                        }
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    pk.z = (uint32_t)f32_to_bf16(v[4 % CPL]) | ((uint32_t)f32_to_bf16(v[5 % CPL]) << 16);
+                    pk.w = (uint32_t)f32_to_bf16(v[6 % CPL]) | ((uint32_t)f32_to_bf16(v[7 % CPL]) << 16);
+                }
+                if (c_lane + CPL <= p.Cout) {
+                    *(u32x4*)dst = pk;
+                } else {   // ragged channel tail
+                    for (int e = 0; c_lane + e < p.Cout; ++e) {
+                        if constexpr (DT == ODAMD_DTYPE_F32) ((float*)dst)[e] = v[e];
+                        else ((uint16_t*)dst)[e] = f32_to_bf16(v[e]);
+                    }
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
+#undef ODAMD_FETCH
+#undef ODAMD_COMMIT
 
 // ------------------------------------------------------------------------------------------
 // first layer: float32 NCHW image, 3 input channels, 3x3 stride 1 -> NHWC activations.
@@ -417,7 +512,7 @@ struct TileChoice { int th, tw, ih, iw; bool ok; };
 
 // Pick the output patch (TH x TW <= npix pixels) that stages the fewest input pixels overall
 // and whose halo patch + weight slab fit in LDS.
-TileChoice choose_tile(int Ho, int Wo, int npix, int ks, int st, int ps, size_t w_bytes) {
+TileChoice choose_tile(int Ho, int Wo, int npix, int ks, int st, int ps, size_t w_bytes, int max_pix) {
     const int cand[] = {Wo, 64, 40, 32, 20, 16, 8};
     TileChoice best = {0, 0, 0, 0, false};
     double best_cost = 1e30;
@@ -427,6 +522,7 @@ TileChoice choose_tile(int Ho, int Wo, int npix, int ks, int st, int ps, size_t 
         if (th > Ho) th = Ho;
         if (th < 1) continue;
         const int ih = (th - 1) * st + ks, iw = (tw - 1) * st + ks;
+        if (ih * iw > max_pix) continue;
         if ((((size_t)ih * iw * ps + 255) & ~(size_t)255) + w_bytes > (size_t)LDS_LIMIT) continue;
         const double tiles = (double)((Wo + tw - 1) / tw) * ((Ho + th - 1) / th);
         const double cost = tiles * (ih * iw + 0.25 * npix);  // staged pixels + a share for idle lanes
@@ -435,39 +531,46 @@ TileChoice choose_tile(int Ho, int Wo, int npix, int ks, int st, int ps, size_t 
     return best;
 }
 
-template <int DT, int KS, int ST, int CG, int PG, int WP, int WC, int CKB>
+template <int DT, int KS, int ST, int CG, int PG, int WP, int WC, int CKB, bool POOL>
 int launch_conv(ConvP p, hipStream_t st) {
+    constexpr int ES = Elem<DT>::SIZE;
     constexpr int PS = CKB + 16, WRS = KS * KS * CKB + 16;
     const size_t w_bytes = (size_t)32 * CG * WRS;
-    TileChoice t = choose_tile(p.Ho, p.Wo, 32 * PG, KS, ST, PS, w_bytes);
+    TileChoice t = choose_tile(p.Ho, p.Wo, 32 * PG, KS, ST, PS, w_bytes, max_in_pix(KS, ST, PG));
     if (!t.ok) return ODAMD_E_SHAPE;
     p.TH = t.th; p.TW = t.tw; p.IH = t.ih; p.IW = t.iw;
     p.tiles_x = (p.Wo + t.tw - 1) / t.tw;
     p.tiles_y = (p.Ho + t.th - 1) / t.th;
     p.ncb = (p.Cout + 32 * CG - 1) / (32 * CG);
     p.nblocks = p.B * p.tiles_x * p.tiles_y * p.ncb;
-    const size_t lds = (((size_t)t.ih * t.iw * PS + 255) & ~(size_t)255) + w_bytes;
-    conv_igemm_kernel<DT, KS, ST, CG, PG, WP, WC, CKB><<<p.nblocks, 256, lds, st>>>(p);
+    size_t lds = (((size_t)t.ih * t.iw * PS + 255) & ~(size_t)255) + w_bytes;
+    const size_t epi = (size_t)4 * 32 * ((CG / WC) * 32 * 4 + 16);    // the waves' f32 transpose slices
+    if (lds < epi) lds = epi;
+    conv_igemm_kernel<DT, KS, ST, CG, PG, WP, WC, CKB, POOL><<<p.nblocks, 256, lds, st>>>(p);
     return (int)hipGetLastError();
 }
 
-template <int DT, int KS, int ST, int CKB>
+template <int DT, int KS, int ST, int CKB, bool POOL>
 int dispatch_cg(const ConvP& p, hipStream_t st) {
-    constexpr int PG = ST == 2 ? 4 : 8;
-    if (p.Cout <= 32) return launch_conv<DT, KS, ST, 1, PG, 4, 1, CKB>(p, st);
-    if (p.Cout <= 64) return launch_conv<DT, KS, ST, 2, PG, 4, 1, CKB>(p, st);
-    return launch_conv<DT, KS, ST, 4, PG, 2, 2, CKB>(p, st);
+    if (p.Cout <= 32) return launch_conv<DT, KS, ST, 1, ST == 2 ? 4 : 8, 4, 1, CKB, POOL>(p, st);
+    if (p.Cout <= 64) return launch_conv<DT, KS, ST, 2, ST == 2 ? 4 : 8, 4, 1, CKB, POOL>(p, st);
+    return launch_conv<DT, KS, ST, 4, 4, 2, 2, CKB, POOL>(p, st);
 }
 
 template <int DT>
 int dispatch_conv(const ConvP& p, int ks, int stride, hipStream_t st) {
     const int cin_bytes = p.Cin * Elem<DT>::SIZE;
     if (ks == 1 && stride == 1) {
-        if (cin_bytes % 64 == 0) return dispatch_cg<DT, 1, 1, 64>(p, st);
-        return dispatch_cg<DT, 1, 1, 32>(p, st);
+        if (p.pool) {
+            if (cin_bytes % 64 == 0) return dispatch_cg<DT, 1, 1, 64, true>(p, st);
+            return dispatch_cg<DT, 1, 1, 32, true>(p, st);
+        }
+        if (cin_bytes % 128 == 0) return dispatch_cg<DT, 1, 1, 128, false>(p, st);
+        if (cin_bytes % 64 == 0) return dispatch_cg<DT, 1, 1, 64, false>(p, st);
+        return dispatch_cg<DT, 1, 1, 32, false>(p, st);
     }
-    if (ks == 3 && stride == 1) return dispatch_cg<DT, 3, 1, 32>(p, st);
-    if (ks == 3 && stride == 2) return dispatch_cg<DT, 3, 2, 32>(p, st);
+    if (ks == 3 && stride == 1) return dispatch_cg<DT, 3, 1, 32, false>(p, st);
+    if (ks == 3 && stride == 2) return dispatch_cg<DT, 3, 2, 32, false>(p, st);
     return ODAMD_E_ARG;
 }
 
