@@ -109,40 +109,42 @@ __device__ __forceinline__ u64 make_key(float score, int row) {
 
 constexpr int FILTER_THREADS = 256;
 
-// SRC == 0: `rows` is the deployed (B,R,K) tensor.  SRC == 1: rows come from the raw heads and
-// are decoded + sigmoided while they sit in LDS.  SRC == 2: rows are already (x_min,y_min,w,h,..)
-// and every row is a candidate (the stand-alone _nms of predict.py:82-92).
-// Each workgroup stages `rows_stage` whole rows in LDS with coalesced loads (row stride padded
-// to an odd number of words so the per-row walk below is bank-conflict free), then one lane
-// per row evaluates predict.py:68-70,83.
+// Where the rows of a filter launch come from: up to three contiguous row ranges ("scales").
+// SRC 0/2 use one range (the (B,R,K) tensor), SRC 1 one range per raw head.
+struct FilterSrc {
+    const float* base[3];   // first row of the range in image 0
+    int rows_in[3];         // rows per image in the range
+    int row_first[3];       // global row index of the range's first row
+    int stage_first[3];     // first workgroup (blockIdx.x) of the range
+};
+
+// SRC == 0: rows are the deployed (B,R,K) tensor.  SRC == 1: rows are RAW head rows; decode and
+// sigmoid are evaluated per surviving row.  SRC == 2: rows are already (x_min,y_min,w,h,..) and
+// every row is a candidate (the stand-alone _nms of predict.py:82-92).
+// A workgroup copies `rows_stage` whole rows of one range into LDS with coalesced loads (row
+// stride padded to an odd number of words, so the per-row walk is bank-conflict free); then one
+// lane per row evaluates predict.py:68-70,83: objectness first, so a rejected row costs one exp.
 template <int SRC>
 __global__ void __launch_bounds__(FILTER_THREADS)
-filter_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdim, int rows_stage, float conf_thr,
+filter_kernel(FilterSrc fs, DecodeGeom g, int rows, int kdim, int rows_stage, float conf_thr,
               float4* __restrict__ rowbox, u64* __restrict__ keys, int n_pad, int* __restrict__ count) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.y;
-    const int row0 = blockIdx.x * rows_stage;
-    const int nrow = min(rows_stage, rows - row0);
+    const int bx = blockIdx.x;
+    const int s = bx >= fs.stage_first[2] ? 2 : (bx >= fs.stage_first[1] ? 1 : 0);
+    const int lrow0 = (bx - fs.stage_first[s]) * rows_stage;
+    const int nrow = min(rows_stage, fs.rows_in[s] - lrow0);
     if (nrow <= 0) return;
+    const int row0 = fs.row_first[s] + lrow0;
     const int ldk = kdim | 1;
-    // stage rows [row0, row0+nrow)
-    if (SRC != 1) {
-        const float* src = pred + ((size_t)b * rows + row0) * kdim;
+    {   // coalesced copy, (row, column) advanced incrementally: no division per element
+        const float* src = fs.base[s] + ((size_t)b * fs.rows_in[s] + lrow0) * kdim;
+        int r = threadIdx.x / kdim, k = threadIdx.x - r * kdim;
+        const int dr = FILTER_THREADS / kdim, dk = FILTER_THREADS - dr * kdim;
         for (int f = threadIdx.x; f < nrow * kdim; f += FILTER_THREADS) {
-            const int r = f / kdim, k = f - r * kdim;
             lds[r * ldk + k] = src[f];
-        }
-    } else {
-        for (int f = threadIdx.x; f < nrow * kdim; f += FILTER_THREADS) {
-            const int r = f / kdim, k = f - r * kdim;
-            const int row = row0 + r;
-            const int s = row >= g.rows_before[2] ? 2 : (row >= g.rows_before[1] ? 1 : 0);
-            const int lrow = row - g.rows_before[s];
-            const int hw = g.h[s] * g.w[s];
-            const int a = lrow / hw, cell = lrow - a * hw;
-            const int y = cell / g.w[s], x = cell - y * g.w[s];
-            const float raw = g.head[s][((size_t)b * g.n_anchor * hw + lrow) * kdim + k];
-            lds[r * ldk + k] = decode_value(g, s, k, a, y, x, raw);
+            r += dr; k += dk;
+            if (k >= kdim) { k -= kdim; ++r; }
         }
     }
     __syncthreads();
@@ -151,16 +153,29 @@ filter_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdim, 
         u64 key = 0;
         if (r < nrow) {
             const float* p = lds + r * ldk;
-            const float bw = p[2], bh = p[3];
-            const float xmin = SRC == 2 ? p[0] : p[0] - bw / 2.0f;
-            const float ymin = SRC == 2 ? p[1] : p[1] - bh / 2.0f;
-            const float conf = p[4];
-            pass = SRC == 2 || ((conf > conf_thr) && (xmin > 0.0f) && (ymin > 0.0f));
-            if (pass) {
-                float m = p[5];
-                for (int k = 6; k < kdim; ++k) m = fmaxf(m, p[k]);
-                key = make_key(conf * m, row0 + r);
-                rowbox[(size_t)b * rows + row0 + r] = make_float4(xmin, ymin, bw, bh);
+            float conf = p[4];
+            if (SRC == 1) conf = sigmoid_f32(conf);
+            if (SRC == 2 || conf > conf_thr) {
+                float cx = p[0], cy = p[1], bw = p[2], bh = p[3];
+                if (SRC == 1) {
+                    const int lrow = lrow0 + r;
+                    const int hw = g.h[s] * g.w[s];
+                    const int a = lrow / hw, cell = lrow - a * hw;
+                    const int y = cell / g.w[s], x = cell - y * g.w[s];
+                    cx = decode_value(g, s, 0, a, y, x, cx);
+                    cy = decode_value(g, s, 1, a, y, x, cy);
+                    bw = decode_value(g, s, 2, a, y, x, bw);
+                    bh = decode_value(g, s, 3, a, y, x, bh);
+                }
+                const float xmin = SRC == 2 ? cx : cx - bw / 2.0f;
+                const float ymin = SRC == 2 ? cy : cy - bh / 2.0f;
+                pass = SRC == 2 || ((xmin > 0.0f) && (ymin > 0.0f));
+                if (pass) {
+                    float m = SRC == 1 ? sigmoid_f32(p[5]) : p[5];
+                    for (int k = 6; k < kdim; ++k) m = fmaxf(m, SRC == 1 ? sigmoid_f32(p[k]) : p[k]);
+                    key = make_key(conf * m, row0 + r);
+                    rowbox[(size_t)b * rows + row0 + r] = make_float4(xmin, ymin, bw, bh);
+                }
             }
         }
         // wave-level compaction: one atomic per wave, lanes take consecutive slots
@@ -253,14 +268,33 @@ __device__ __forceinline__ bool suppresses(const float4 a, const float4 c, float
 
 constexpr int MASK_WAVES = 4;
 
+// Per-box values derived once: corners, area and whether the cheap overlap test is valid for it.
+struct BoxEx { float x2, y2, area, special; };
+__device__ __forceinline__ BoxEx box_ex(const float4 c) {
+    BoxEx e;
+    e.x2 = c.x + c.z;
+    e.y2 = c.y + c.w;
+    e.area = c.z * c.w;
+    // "regular" box: positive extent that survives rounding, positive finite area.  For two
+    // regular boxes without overlap the reference arithmetic gives inter = +0, union > 0, IoU = +0.
+    const bool regular = (e.x2 > c.x) && (e.y2 > c.y) && (e.area > 0.0f) && (e.area < 3.0e38f) &&
+                         (fabsf(c.x) < 3.0e38f) && (fabsf(c.y) < 3.0e38f) && (e.x2 < 3.0e38f) && (e.y2 < 3.0e38f);
+    e.special = regular ? 0.0f : 1.0f;
+    return e;
+}
+
 // Grid: x = groups of MASK_WAVES column tiles, y = row tiles of this chunk, z = image.
 // Wave w of a workgroup owns the 64x64 tile (row tile, column tile 4*bx + w): lane i holds row
-// box i in registers, the 64 column boxes sit in the wave's 1 KiB LDS slice and are read as
-// broadcasts.  Rows already suppressed by earlier chunks (bit set in `removed`) are skipped.
+// box i in registers, the 64 column boxes sit in the wave's LDS slice and are read as
+// broadcasts.  Most pairs do not overlap at all: four compares decide that for the whole wave
+// (the AND of the compare masks is scalar work) and the exact IoU with its division only runs
+// for columns that overlap some row of the tile.  Rows already suppressed by earlier chunks
+// (bit set in `removed`) are skipped.
 __global__ void __launch_bounds__(64 * MASK_WAVES)
 iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, const u64* __restrict__ removed,
                 int n_pad, int row_begin, float thr, u64* __restrict__ mask, size_t mask_stride_img) {
     __shared__ float4 cols[MASK_WAVES][64];
+    __shared__ float4 colx[MASK_WAVES][64];
     const int b = blockIdx.z;
     const int n = count ? min(count[b], n_pad) : n_pad;
     const int words = n_pad >> 6;
@@ -270,21 +304,41 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
     if (rt * 64 >= n) return;                       // uniform per workgroup
     const bool active = (ct >= rt) && (ct * 64 < n) && (ct < words);
     const float4* boxes = sbox + (size_t)b * n_pad;
-    if (active) cols[wave][lane] = (ct * 64 + lane < n) ? boxes[ct * 64 + lane] : make_float4(0, 0, 0, 0);
+    if (active) {
+        const float4 c = (ct * 64 + lane < n) ? boxes[ct * 64 + lane] : make_float4(0, 0, 0, 0);
+        const BoxEx e = box_ex(c);
+        cols[wave][lane] = c;
+        colx[wave][lane] = make_float4(e.x2, e.y2, e.area, e.special);
+    }
     __syncthreads();
     if (!active) return;
     const int i = rt * 64 + lane;
     u64 word = 0;
     bool live = i < n;
     if (live && removed) live = !((removed[(size_t)b * words + rt] >> lane) & 1ull);
-    if (live) {
-        const float4 a = boxes[i];
-        const int jmax = min(64, n - ct * 64);
+    const u64 live_mask = __ballot(live);
+    if (live_mask) {
+        const float4 a = live ? boxes[i] : make_float4(0, 0, 0, 0);
+        const BoxEx ae = box_ex(a);
+        const bool a_special = ae.special != 0.0f;
+        const bool none_sup = 0.0f < thr;            // IoU == +0 survives iff 0 < thr
+        uint32_t lo = 0, hi = 0;
 #pragma unroll 8
-        for (int j = 0; j < jmax; ++j) {
-            const bool s = suppresses(a, cols[wave][j], thr);
-            word |= (u64)(s && (ct * 64 + j > i)) << j;
+        for (int j = 0; j < 64; ++j) {
+            const float4 c = cols[wave][j];
+            const float4 e = colx[wave][j];
+            const bool overlap = (a.x < e.x) && (c.x < ae.x2) && (a.y < e.y) && (c.y < ae.y2);
+            const bool need = overlap || a_special || (e.w != 0.0f) || !none_sup;
+            bool sup = false;
+            if (__ballot(need && live)) sup = need && suppresses(a, c, thr);
+            if (j < 32) lo |= sup ? (1u << j) : 0u;
+            else hi |= sup ? (1u << (j - 32)) : 0u;
         }
+        word = ((u64)hi << 32) | lo;
+        const int ncol = n - ct * 64;                                     // valid columns of this tile
+        if (ncol < 64) word &= (1ull << ncol) - 1ull;
+        if (ct == rt) word &= lane == 63 ? 0ull : ~((2ull << lane) - 1ull);  // strictly later boxes only
+        if (!live) word = 0;
     }
     mask[(size_t)b * mask_stride_img + (size_t)(i - row_begin) * words + ct] = word;
 }
@@ -293,8 +347,9 @@ constexpr int SCAN_THREADS = 256;
 
 // One workgroup per image.  `removed` (n_pad bits) lives in LDS for the chunk and in global
 // memory between chunks.  Per 64-row tile: wave 0 resolves the tile serially from its 64
-// diagonal words (uniform scalar work), then all threads OR the kept rows' words into the
-// later part of `removed`.
+// diagonal words (uniform scalar work; the words of the NEXT tile are already in flight), then
+// all threads OR the kept rows' words into the later part of `removed`, eight rows per batch
+// of independent loads.
 __global__ void __launch_bounds__(SCAN_THREADS)
 nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int* __restrict__ count,
                 const int* __restrict__ srow, u64* __restrict__ removed_g, int n_pad, int row_begin, int row_end,
@@ -313,11 +368,21 @@ nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int*
     if (threadIdx.x == 0) kept_total = keep_count[b];
     __syncthreads();
     const int lane = threadIdx.x & 63;
+    const int t_begin = row_begin >> 6;
     const int t_end = (min(row_end, n) + 63) >> 6;
-    for (int t = row_begin >> 6; t < t_end; ++t) {
+    u64 diag_next = 0;
+    if (threadIdx.x < 64) {
+        const int i = t_begin * 64 + lane;
+        diag_next = (i < n) ? m[(size_t)(i - row_begin) * words + t_begin] : 0ull;
+    }
+    for (int t = t_begin; t < t_end; ++t) {
         if (threadIdx.x < 64) {
             const int i = t * 64 + lane;
-            const u64 diag = (i < n) ? m[(size_t)(i - row_begin) * words + t] : 0ull;
+            const u64 diag = diag_next;
+            if (t + 1 < t_end) {   // prefetch the next tile's diagonal words
+                const int i2 = i + 64;
+                diag_next = (i2 < n) ? m[(size_t)(i2 - row_begin) * words + t + 1] : 0ull;
+            }
             const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
             u64 alive = ~removed[t];
             if (n - t * 64 < 64) alive &= (1ull << (n - t * 64)) - 1ull;
@@ -344,17 +409,19 @@ nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int*
         }
         __syncthreads();
         const u64 kept = kept_bits;
-        if (kept) {
-            for (int w = t + 1 + threadIdx.x; w < nwords; w += SCAN_THREADS) {
-                u64 acc = 0;
-                u64 kk = kept;
-                while (kk) {
-                    const int q = __ffsll((long long)kk) - 1;
-                    kk &= kk - 1;
-                    acc |= m[(size_t)(t * 64 + q - row_begin) * words + w];
-                }
-                removed[w] |= acc;
+        const u64* mt = m + (size_t)(t * 64 - row_begin) * words;
+        for (int w = t + 1 + threadIdx.x; w < nwords; w += SCAN_THREADS) {
+            u64 acc = 0;
+#pragma unroll
+            for (int q0 = 0; q0 < 64; q0 += 8) {
+                const uint32_t sub = (uint32_t)(kept >> q0) & 0xFFu;
+                if (!sub) continue;
+                u64 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = ((sub >> u) & 1u) ? mt[(size_t)(q0 + u) * words + w] : 0ull;
+                acc |= (v[0] | v[1]) | (v[2] | v[3]) | (v[4] | v[5]) | (v[6] | v[7]);
             }
+            removed[w] |= acc;
         }
         __syncthreads();
     }
@@ -362,7 +429,8 @@ nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int*
     if (threadIdx.x == 0) keep_count[b] = kept_total;
 }
 
-// Kept rows -> output rows (predict.py:74-79).  SRC as in filter_kernel.
+// Kept rows -> output rows (predict.py:74-79).  SRC as in filter_kernel.  One wave per kept row:
+// the row's (scale, anchor, cell) is wave-uniform, lanes walk the K columns.
 template <int SRC>
 __global__ void __launch_bounds__(256)
 emit_rows_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdim, const int* __restrict__ keep_idx,
@@ -372,35 +440,40 @@ emit_rows_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdi
     const int nk = min(keep_count[b], max_keep);
     const float xs = scale_xy ? scale_xy[2 * b] : 1.0f;
     const float ys = scale_xy ? scale_xy[2 * b + 1] : 1.0f;
-    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nk * kdim; f += gridDim.x * blockDim.x) {
-        const int j = f / kdim, k = f - j * kdim;
+    const int lane = threadIdx.x & 63;
+    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < nk; j += gridDim.x * 4) {
         const int row = keep_idx[(size_t)b * max_keep + j];
-        float v[4];
-        const int k0 = k < 4 ? 0 : k, k1 = k < 4 ? 4 : k + 1;
-        float val = 0.f;
-        for (int kk = k0; kk < k1; ++kk) {
-            float x;
-            if (SRC != 1) {
-                x = pred[((size_t)b * rows + row) * kdim + kk];
-            } else {
-                const int s = row >= g.rows_before[2] ? 2 : (row >= g.rows_before[1] ? 1 : 0);
-                const int lrow = row - g.rows_before[s];
-                const int hw = g.h[s] * g.w[s];
-                const int a = lrow / hw, cell = lrow - a * hw;
-                const int y = cell / g.w[s], xx = cell - y * g.w[s];
-                x = decode_value(g, s, kk, a, y, xx, g.head[s][((size_t)b * g.n_anchor * hw + lrow) * kdim + kk]);
+        const float* src;
+        int s = 0, a = 0, y = 0, x = 0;
+        if (SRC != 1) {
+            src = pred + ((size_t)b * rows + row) * kdim;
+        } else {
+            s = row >= g.rows_before[2] ? 2 : (row >= g.rows_before[1] ? 1 : 0);
+            const int lrow = row - g.rows_before[s];
+            const int hw = g.h[s] * g.w[s];
+            a = lrow / hw;
+            const int cell = lrow - a * hw;
+            y = cell / g.w[s];
+            x = cell - y * g.w[s];
+            src = g.head[s] + ((size_t)b * g.n_anchor * hw + lrow) * kdim;
+        }
+        float* dst = out + ((size_t)b * max_keep + j) * kdim;
+        for (int k = lane; k < kdim; k += 64) {
+            float v = src[k];
+            if (SRC == 1) v = decode_value(g, s, k, a, y, x, v);
+            if (SRC != 2 && k < 4) {
+                // x_min = cx - w/2 ; cx' = x_min + w/2 ; scaled.  Same roundings as the reference.
+                if (k < 2) {
+                    float wh = src[k + 2];
+                    if (SRC == 1) wh = decode_value(g, s, k + 2, a, y, x, wh);
+                    const float half = wh / 2.0f;
+                    v = ((v - half) + half) * (k == 0 ? xs : ys);
+                } else {
+                    v = v * (k == 2 ? xs : ys);
+                }
             }
-            if (k < 4) v[kk] = x; else val = x;
+            dst[k] = v;
         }
-        if (SRC == 2) {
-            if (k < 4) val = v[k];
-        } else if (k < 4) {
-            // x_min = cx - w/2 ; cx' = x_min + w/2 ; scaled.  Same roundings as the reference.
-            const float half = v[2 + (k & 1)] / 2.0f;
-            if (k < 2) val = ((v[k] - half) + half) * (k == 0 ? xs : ys);
-            else val = v[k] * (k == 2 ? xs : ys);
-        }
-        out[((size_t)b * max_keep + j) * kdim + k] = val;
     }
 }
 
@@ -518,9 +591,25 @@ int postprocess_impl(const float* pred, const DecodeGeom& g, int batch, int rows
     int rows_stage = (48 * 1024) / (ldk * 4);
     if (rows_stage > FILTER_THREADS) rows_stage = FILTER_THREADS;
     if (rows_stage < 1) return ODAMD_E_ARG;  // more than ~12k classes
-    dim3 fgrid((rows + rows_stage - 1) / rows_stage, batch);
+    FilterSrc fs = {};
+    int nstage = 0;
+    if (SRC == 1) {
+        for (int s = 0; s < 3; ++s) {
+            fs.base[s] = g.head[s];
+            fs.rows_in[s] = g.n_anchor * g.h[s] * g.w[s];
+            fs.row_first[s] = g.rows_before[s];
+            fs.stage_first[s] = nstage;
+            nstage += (fs.rows_in[s] + rows_stage - 1) / rows_stage;
+        }
+    } else {
+        fs.base[0] = pred;
+        fs.rows_in[0] = rows;
+        nstage = (rows + rows_stage - 1) / rows_stage;
+        fs.stage_first[1] = fs.stage_first[2] = nstage;   // ranges 1, 2 are empty
+    }
+    dim3 fgrid(nstage, batch);
     filter_kernel<SRC><<<fgrid, FILTER_THREADS, (size_t)rows_stage * ldk * 4, st>>>(
-        pred, g, rows, kdim, rows_stage, conf_thr, w.rowbox, w.keys, n_pad, w.count);
+        fs, g, rows, kdim, rows_stage, conf_thr, w.rowbox, w.keys, n_pad, w.count);
     if ((rc = sort_keys(w.keys, batch, n_pad, st))) return rc;
     gather_sorted_kernel<<<dim3((n_pad + 255) / 256, batch), 256, 0, st>>>(w.keys, w.rowbox, w.count, rows, n_pad,
                                                                            w.sbox, w.srow);
@@ -528,8 +617,8 @@ int postprocess_impl(const float* pred, const DecodeGeom& g, int batch, int rows
     if (cand_count)
         if ((rc = (int)hipMemcpyAsync(cand_count, w.count, (size_t)batch * 4, hipMemcpyDeviceToDevice, st))) return rc;
     if (out_rows) {
-        const int gx = (max_keep * kdim + 255) / 256;
-        emit_rows_kernel<SRC><<<dim3(gx > 1024 ? 1024 : gx, batch), 256, 0, st>>>(pred, g, rows, kdim, out_idx,
+        const int gx = (max_keep + 3) / 4;
+        emit_rows_kernel<SRC><<<dim3(gx > 512 ? 512 : gx, batch), 256, 0, st>>>(pred, g, rows, kdim, out_idx,
                                                                                    out_count, max_keep, scale_xy,
                                                                                    out_rows);
     }
