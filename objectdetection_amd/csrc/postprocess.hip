@@ -268,6 +268,10 @@ __device__ __forceinline__ bool suppresses(const float4 a, const float4 c, float
 
 constexpr int MASK_WAVES = 4;
 
+// Bare v_max_f32 / v_min_f32 (no NaN canonicalisation): only used where NaN cannot decide.
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 // Per-box values derived once: corners, area and whether the cheap overlap test is valid for it.
 struct BoxEx { float x2, y2, area, special; };
 __device__ __forceinline__ BoxEx box_ex(const float4 c) {
@@ -283,27 +287,30 @@ __device__ __forceinline__ BoxEx box_ex(const float4 c) {
     return e;
 }
 
-// Grid: x = groups of MASK_WAVES column tiles, y = row tiles of this chunk, z = image.
-// Wave w of a workgroup owns the 64x64 tile (row tile, column tile 4*bx + w): lane i holds row
-// box i in registers, the 64 column boxes sit in the wave's LDS slice and are read as
-// broadcasts.  Most pairs do not overlap at all: four compares decide that for the whole wave
-// (the AND of the compare masks is scalar work) and the exact IoU with its division only runs
-// for columns that overlap some row of the tile.  Rows already suppressed by earlier chunks
-// (bit set in `removed`) are skipped.
+// Grid: (GX, GY, image).  The number of candidates is only known on the device, so a fixed, small
+// grid walks the tiles that exist: workgroup (bx, by) takes row tiles by, by+GY, ... of this chunk
+// and, for each, column-tile groups bx, bx+GX, ... at or right of the diagonal.
+// Wave w of a workgroup owns the 64x64 tile (row tile, column tile 4*group + w): lane i holds row
+// box i in registers, the 64 column boxes sit in the wave's LDS slice and are read as broadcasts.
+// Rows already suppressed by earlier chunks (bit set in `removed`) are skipped.
 __global__ void __launch_bounds__(64 * MASK_WAVES)
 iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, const u64* __restrict__ removed,
-                int n_pad, int row_begin, float thr, u64* __restrict__ mask, size_t mask_stride_img) {
+                int n_pad, int row_begin, int row_end, float thr, u64* __restrict__ mask, size_t mask_stride_img) {
     __shared__ float4 cols[MASK_WAVES][64];
     __shared__ float4 colx[MASK_WAVES][64];
     const int b = blockIdx.z;
     const int n = count ? min(count[b], n_pad) : n_pad;
     const int words = n_pad >> 6;
+    const int nwords = (n + 63) >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rt = (row_begin >> 6) + blockIdx.y;   // global row tile
-    const int ct = blockIdx.x * MASK_WAVES + wave;  // global column tile
-    if (rt * 64 >= n) return;                       // uniform per workgroup
-    const bool active = (ct >= rt) && (ct * 64 < n) && (ct < words);
+    const int rt_end = (min(row_end, n) + 63) >> 6;
+    const int ngroups = (nwords + MASK_WAVES - 1) / MASK_WAVES;
     const float4* boxes = sbox + (size_t)b * n_pad;
+    for (int rt = (row_begin >> 6) + blockIdx.y; rt < rt_end; rt += gridDim.y)
+    for (int grp = rt / MASK_WAVES + blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int ct = grp * MASK_WAVES + wave;  // global column tile
+    const bool active = (ct >= rt) && (ct < nwords);
+    __syncthreads();                         // previous iteration's LDS reads are done
     if (active) {
         const float4 c = (ct * 64 + lane < n) ? boxes[ct * 64 + lane] : make_float4(0, 0, 0, 0);
         const BoxEx e = box_ex(c);
@@ -311,7 +318,7 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
         colx[wave][lane] = make_float4(e.x2, e.y2, e.area, e.special);
     }
     __syncthreads();
-    if (!active) return;
+    if (!active) continue;
     const int i = rt * 64 + lane;
     u64 word = 0;
     bool live = i < n;
@@ -321,16 +328,29 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
         const float4 a = live ? boxes[i] : make_float4(0, 0, 0, 0);
         const BoxEx ae = box_ex(a);
         const bool a_special = ae.special != 0.0f;
-        const bool none_sup = 0.0f < thr;            // IoU == +0 survives iff 0 < thr
+        // Division-free decision with a guard band: for regular boxes
+        //   inter < union*thr*(1-2^-20)  =>  fl(inter/union) <  thr   (survives)
+        //   inter > union*thr*(1+2^-20)  =>  fl(inter/union) >= thr   (suppressed)
+        // (the band is 2^4 times wider than all roundings involved); anything else -- a pair inside
+        // the band, an irregular box, a tiny union, thr <= 0 -- takes the exact reference arithmetic.
+        const bool thr_ok = thr > 1.0e-30f && thr < 1.0e30f;
+        const float thr_lo = thr * (1.0f - 9.5367431640625e-7f), thr_hi = thr * (1.0f + 9.5367431640625e-7f);
         uint32_t lo = 0, hi = 0;
 #pragma unroll 8
         for (int j = 0; j < 64; ++j) {
             const float4 c = cols[wave][j];
             const float4 e = colx[wave][j];
-            const bool overlap = (a.x < e.x) && (c.x < ae.x2) && (a.y < e.y) && (c.y < ae.y2);
-            const bool need = overlap || a_special || (e.w != 0.0f) || !none_sup;
-            bool sup = false;
-            if (__ballot(need && live)) sup = need && suppresses(a, c, thr);
+            const float x1 = vmax(a.x, c.x), y1 = vmax(a.y, c.y);
+            const float x2 = vmin(ae.x2, e.x), y2 = vmin(ae.y2, e.y);
+            const float inter = vmax(x2 - x1, 0.0f) * vmax(y2 - y1, 0.0f);
+            const float uni = ae.area + e.z - inter;
+            const bool big = uni > 1.0e-30f;
+            const bool keep_sure = (inter < uni * thr_lo) && big;
+            bool sup = (inter > uni * thr_hi) && big;
+            const bool amb = !(keep_sure || sup) || a_special || (e.w != 0.0f) || !thr_ok;
+            if (__ballot(amb && live)) {
+                if (amb) sup = suppresses(a, c, thr);
+            }
             if (j < 32) lo |= sup ? (1u << j) : 0u;
             else hi |= sup ? (1u << (j - 32)) : 0u;
         }
@@ -341,6 +361,7 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
         if (!live) word = 0;
     }
     mask[(size_t)b * mask_stride_img + (size_t)(i - row_begin) * words + ct] = word;
+    }
 }
 
 constexpr int SCAN_THREADS = 256;
@@ -561,8 +582,9 @@ int run_nms(const Workspace& w, const int* count, int batch, int n_pad, float io
     const int words = n_pad / 64;
     for (int r0 = 0; r0 < n_pad; r0 += w.chunk_rows) {
         const int r1 = r0 + w.chunk_rows < n_pad ? r0 + w.chunk_rows : n_pad;
-        dim3 grid((words + MASK_WAVES - 1) / MASK_WAVES, (r1 - r0) / 64, batch);
-        iou_mask_kernel<<<grid, 64 * MASK_WAVES, 0, st>>>(w.sbox, count, w.removed, n_pad, r0, iou_thr, w.mask,
+        const int gx = (words + MASK_WAVES - 1) / MASK_WAVES, gy = (r1 - r0) / 64;
+        dim3 grid(gx < 8 ? gx : 8, gy < 32 ? gy : 32, batch);
+        iou_mask_kernel<<<grid, 64 * MASK_WAVES, 0, st>>>(w.sbox, count, w.removed, n_pad, r0, r1, iou_thr, w.mask,
                                                            w.mask_stride_img);
         nms_scan_kernel<<<batch, SCAN_THREADS, (size_t)words * 8, st>>>(w.mask, w.mask_stride_img, count, w.srow,
                                                                         w.removed, n_pad, r0, r1, out_idx, out_count,
@@ -705,9 +727,10 @@ int odamd_iou_mask(const float* boxes_xywh, int n, float iou_thr, uint64_t* mask
     if (!boxes_xywh || !mask || n < 64 || (n & 63)) return ODAMD_E_ARG;
     if (((uintptr_t)boxes_xywh & 15) != 0) return ODAMD_E_ALIGN;
     const int words = n / 64;
-    dim3 grid((words + MASK_WAVES - 1) / MASK_WAVES, words, 1);
+    const int gx = (words + MASK_WAVES - 1) / MASK_WAVES;
+    dim3 grid(gx < 8 ? gx : 8, words < 64 ? words : 64, 1);
     iou_mask_kernel<<<grid, 64 * MASK_WAVES, 0, (hipStream_t)stream>>>((const float4*)boxes_xywh, nullptr, nullptr, n, 0,
-                                                                       iou_thr, (u64*)mask, 0);
+                                                                       n, iou_thr, (u64*)mask, 0);
     return (int)hipGetLastError();
 }
 
