@@ -405,7 +405,10 @@ nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int*
                 diag_next = (i2 < n) ? m[(size_t)(i2 - row_begin) * words + t + 1] : 0ull;
             }
             const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
-            u64 alive = ~removed[t];
+            const u64 rem = removed[t];
+            // wave-uniform state in scalar registers: the 64-step chain below is scalar work
+            u64 alive = ~(((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rem >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rem));
             if (n - t * 64 < 64) alive &= (1ull << (n - t * 64)) - 1ull;
             u64 kept = 0;
 #pragma unroll
@@ -432,15 +435,16 @@ nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int*
         const u64 kept = kept_bits;
         const u64* mt = m + (size_t)(t * 64 - row_begin) * words;
         for (int w = t + 1 + threadIdx.x; w < nwords; w += SCAN_THREADS) {
+            // all 64 row words in flight at once (two batches of 32); rows that were not kept are
+            // loaded too and masked out, which keeps the loads free of branches
             u64 acc = 0;
 #pragma unroll
-            for (int q0 = 0; q0 < 64; q0 += 8) {
-                const uint32_t sub = (uint32_t)(kept >> q0) & 0xFFu;
-                if (!sub) continue;
-                u64 v[8];
+            for (int q0 = 0; q0 < 64; q0 += 32) {
+                u64 v[32];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = ((sub >> u) & 1u) ? mt[(size_t)(q0 + u) * words + w] : 0ull;
-                acc |= (v[0] | v[1]) | (v[2] | v[3]) | (v[4] | v[5]) | (v[6] | v[7]);
+                for (int u = 0; u < 32; ++u) v[u] = mt[(size_t)(q0 + u) * words + w];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) acc |= ((kept >> (q0 + u)) & 1ull) ? v[u] : 0ull;
             }
             removed[w] |= acc;
         }
