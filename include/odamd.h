@@ -109,6 +109,9 @@ int odamd_nms_rows(const float* rows_xywh, int batch, int rows, int kdim, float 
 /* Building blocks of the chain, exported for tests and for callers that bring their own
  * candidate set.  boxes: (n) float4 {x_min,y_min,w,h}; bit j of mask word (i, j/64) is set
  * iff j > i and not (IoU(i,j) < iou_thr).  predict.py:33-41. */
+/* predict_class.iou (predict.py:33-41): out[i] = IoU(a[i], b[i]) for (x_min,y_min,w,h) float4 boxes;
+ * na or nb may be 1 (that box is broadcast). */
+int odamd_iou_pairs(const float* a_xywh, int na, const float* b_xywh, int nb, float* out, int n, void* stream);
 int odamd_iou_mask(const float* boxes_xywh, int n, float iou_thr, uint64_t* mask, void* stream);
 
 /* ------------------------------------------------------------------------------------------

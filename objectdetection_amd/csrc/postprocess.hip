@@ -287,6 +287,18 @@ __device__ __forceinline__ BoxEx box_ex(const float4 c) {
     return e;
 }
 
+// predict_class.iou (predict.py:33-41): IoU of box i of `a` (or its only box) against box i of `b`.
+__global__ void __launch_bounds__(256) iou_pairs_kernel(const float4* __restrict__ a, int na, const float4* __restrict__ b,
+                                                        int nb, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = a[na == 1 ? 0 : i], c = b[nb == 1 ? 0 : i];
+    const float x1 = fmaxf(p.x, c.x), y1 = fmaxf(p.y, c.y);
+    const float x2 = fminf(p.x + p.z, c.x + c.z), y2 = fminf(p.y + p.w, c.y + c.w);
+    const float inter = fmaxf(x2 - x1, 0.0f) * fmaxf(y2 - y1, 0.0f);
+    out[i] = inter / (p.z * p.w + c.z * c.w - inter);
+}
+
 // Grid: (GX, GY, image).  The number of candidates is only known on the device, so a fixed, small
 // grid walks the tiles that exist: workgroup (bx, by) takes row tiles by, by+GY, ... of this chunk
 // and, for each, column-tile groups bx, bx+GX, ... at or right of the diagonal.
@@ -725,6 +737,15 @@ int odamd_nms_rows(const float* rows_xywh, int batch, int rows, int kdim, float 
     DecodeGeom g = {};
     return postprocess_impl<2>(rows_xywh, g, batch, rows, kdim, 0.0f, iou_thr, nullptr, n_pad, out_rows, out_idx,
                                out_count, nullptr, max_keep, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int odamd_iou_pairs(const float* a_xywh, int na, const float* b_xywh, int nb, float* out, int n, void* stream) {
+    if (!a_xywh || !b_xywh || !out || n < 1 || na < 1 || nb < 1) return ODAMD_E_ARG;
+    if ((na != 1 && na < n) || (nb != 1 && nb < n)) return ODAMD_E_SHAPE;
+    if (((uintptr_t)a_xywh & 15) || ((uintptr_t)b_xywh & 15)) return ODAMD_E_ALIGN;
+    iou_pairs_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>((const float4*)a_xywh, na, (const float4*)b_xywh,
+                                                                       nb, out, n);
+    return (int)hipGetLastError();
 }
 
 int odamd_iou_mask(const float* boxes_xywh, int n, float iou_thr, uint64_t* mask, void* stream) {

@@ -1,0 +1,113 @@
+"""Inference entry point, API-compatible with the reference's predict.py (predict_class with
+predict / _decode / _nms / iou), running the network and the whole post-processing on the GPU.
+
+Reference: predict.py:22-92.  Differences that no caller on the path observes are deliberate:
+the numpy input of `_decode` is not modified in place (predict.py:68 overwrites the caller's
+array), and a whole batch can be post-processed at once (`predict_batch`); the reference parses a
+`--batch` flag (predict.py:11) but only ever decodes image 0 (predict.py:56).
+"""
+import argparse
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import engine, postprocess as _post
+from ._lib import lib, check
+from .model.layer import deploy
+
+parser = argparse.ArgumentParser(description='model prediction')
+parser.add_argument('--input_size', default=640, type=int)
+parser.add_argument('--batch', default=1, type=int)
+parser.add_argument('--device', default='cuda', type=str)
+parser.add_argument('--float16', default=True, type=bool)
+parser.add_argument('--confidence_threshold', default=0.5, type=float)
+parser.add_argument('--iou_threshold', default=0.5, type=float)
+args, _ = parser.parse_known_args()
+
+
+class predict_class:
+    def __init__(self, model_path, args=args, model=None):
+        """`model_path`: checkpoint written by training (a dict holding the module under 'model').
+        `model`: alternatively an already built yolov7 module (no file needed)."""
+        if not torch.cuda.is_available():
+            raise RuntimeError('objectdetection_amd.predict needs a GPU: there is no CPU fallback')
+        self.device = args.device
+        self.float16 = args.float16
+        self.input_size = args.input_size
+        self.confidence_threshold = args.confidence_threshold
+        self.iou_threshold = args.iou_threshold
+        if model is None:
+            model = torch.load(model_path, map_location='cpu', weights_only=False)['model']
+        self.model = deploy(model).eval().to(args.device)
+        # the reference runs fp16 on a GPU (predict.py:18,31); the MI355X build computes in bf16
+        # on the matrix cores instead (float32 parameters stay the master copy)
+        self.dtype = 'bf16' if args.float16 else 'f32'
+
+    # ---- predict.py:33-41 -------------------------------------------------------------------
+    @staticmethod
+    def iou(pred, label):
+        """IoU of (x_min,y_min,w,h) boxes, row-wise with broadcasting of a single `pred` row."""
+        a = torch.as_tensor(np.ascontiguousarray(pred[:, 0:4], dtype=np.float32)).cuda()
+        b = torch.as_tensor(np.ascontiguousarray(label[:, 0:4], dtype=np.float32)).cuda()
+        n = max(len(a), len(b))
+        out = torch.empty(n, dtype=torch.float32, device='cuda')
+        check(lib.odamd_iou_pairs(a.data_ptr(), len(a), b.data_ptr(), len(b), out.data_ptr(), n,
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'iou_pairs')
+        return out.cpu().numpy()
+
+    # ---- predict.py:53-65 -------------------------------------------------------------------
+    def _image_process(self, image):
+        if image.shape[0] != self.input_size or image.shape[1] != self.input_size:
+            import cv2  # host image I/O only; not part of the accelerated path
+            image = cv2.resize(image, (self.input_size, self.input_size))
+        image = image.astype(np.float32) / 255
+        return image[np.newaxis].transpose(0, 3, 1, 2)
+
+    def _forward_heads(self, tensor):
+        engine.set_compute_dtype(self.dtype)
+        try:
+            return self.model.model.head_tensors(tensor)
+        finally:
+            engine.set_compute_dtype(None)
+
+    def predict(self, image):
+        tensor = torch.from_numpy(np.ascontiguousarray(self._image_process(image))).to(self.device)
+        scale = torch.tensor([[image.shape[1] / self.input_size, image.shape[0] / self.input_size]],
+                             dtype=torch.float32, device=self.device)
+        with torch.no_grad():
+            if hasattr(self.model.model, 'head_tensors'):
+                heads = self._forward_heads(tensor)
+                dec = self.model.model.decode
+                res = _post.postprocess_heads([h[:1] for h in heads], dec.input_size, dec.anchor_rel,
+                                              self.confidence_threshold, self.iou_threshold, scale)
+            else:
+                res = _post.postprocess(self.model(tensor)[:1].float(), self.confidence_threshold, self.iou_threshold,
+                                        scale)
+        return res.per_image()[0][0]
+
+    def predict_batch(self, tensor, shapes=None):
+        """(B,3,S,S) float tensor already on the device -> list of (kept,K) arrays / None."""
+        b = tensor.shape[0]
+        if shapes is None:
+            scale = None
+        else:
+            scale = torch.tensor([[s[1] / self.input_size, s[0] / self.input_size] for s in shapes],
+                                 dtype=torch.float32, device=tensor.device)
+        with torch.no_grad():
+            heads = self._forward_heads(tensor)
+            dec = self.model.model.decode
+            res = _post.postprocess_heads(heads, dec.input_size, dec.anchor_rel, self.confidence_threshold,
+                                          self.iou_threshold, scale)
+        return [r for r, _ in res.per_image()][:b]
+
+    # ---- predict.py:67-92 -------------------------------------------------------------------
+    def _decode(self, pred, shape):
+        p = torch.as_tensor(np.ascontiguousarray(pred, dtype=np.float32)).cuda()
+        scale = torch.tensor([[shape[1] / self.input_size, shape[0] / self.input_size]], dtype=torch.float32,
+                             device='cuda')
+        return _post.postprocess(p, self.confidence_threshold, self.iou_threshold, scale).per_image()[0][0]
+
+    def _nms(self, pred):
+        p = torch.as_tensor(np.ascontiguousarray(pred, dtype=np.float32)).cuda()
+        return _post.nms_rows(p, self.iou_threshold).per_image()[0][0]
