@@ -139,14 +139,19 @@ typedef struct {
     int dtype;         /* ODAMD_DTYPE_* of x, w (and of y when out_nchw_f32 == 0) */
     int in_pool2;      /* 1: input is max-pooled 2x2/2 on the fly (mp.maxpool0, model/layer.py:140) */
     int out_nchw_f32;  /* 1: y is float32 NCHW (B, cout, Ho, Wo) -- the head layout */
+    int in_upzero2;    /* 1: input is zero-upsampled x2 on the fly (value at even (y,x), zero elsewhere): with
+                          flipped, transposed weights this is the data gradient of a stride-2 3x3 convolution */
+    int accumulate;    /* 1: NHWC output is added to the destination (gradient accumulation) */
 } odamd_conv_desc;
 
 int odamd_conv_forward(const odamd_conv_desc* d, void* stream);
 
 /* First layer: float32 NCHW image (B,3,H,W) -> NHWC activations; replaces cbs0 of
- * yolov7.forward (model/yolov7.py:114) in eval mode.  w: [cout][ky][kx][3] float32. */
+ * yolov7.forward (model/yolov7.py:114).  w: [cout][ky][kx][3] float32; scale/shift may both be
+ * NULL (raw convolution for train-mode BatchNorm); act: 0 none, 1 SiLU. */
 int odamd_conv_first_forward(const float* image, const float* w, const float* scale, const float* shift,
-                             void* y, int batch, int h, int w_in, int cout, int y_ld, int dtype, void* stream);
+                             void* y, int batch, int h, int w_in, int cout, int y_ld, int act, int dtype,
+                             void* stream);
 
 /* MaxPool2d(2,2) (model/layer.py:125), three stride-1 max pools k=5,9,13 of one tensor
  * (model/layer.py:215-217) and nearest Upsample x2 (model/yolov7.py:32), all NHWC, each
@@ -164,6 +169,76 @@ int odamd_nchw_to_nhwc(const float* x, void* y, int batch, int c, int h, int w, 
                        void* stream);
 int odamd_nhwc_to_nchw(const void* x, float* y, int batch, int c, int h, int w, int x_ld, int y_c, int dtype,
                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training step (train_class.py:193-218): train-mode BatchNorm + SiLU, their backward, pooling /
+ * upsample backward, weight gradients, loss, optimizer.  Data gradients of convolutions reuse
+ * odamd_conv_forward with flipped, transposed weights (odamd_pack_weights builds them).
+ */
+
+/* Workspace for the per-channel reductions below (BN backward needs 2*channels floats more). */
+size_t odamd_bn_workspace_bytes(int channels);
+
+/* cbs.bn + cbs.silu in train mode (model/layer.py:14-15): batch statistics of the raw convolution
+ * output y over npix = B*H*W pixels, running buffers updated (momentum, unbiased variance),
+ * out = silu(y*scale + shift) written with pixel stride out_ld.  mean/invstd/scale/shift (channels
+ * floats each) are kept for the backward pass. */
+int odamd_bn_train_forward(const void* y, int y_ld, void* out, int out_ld, size_t npix, int channels,
+                           const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                           float* running_var, float* mean, float* invstd, float* scale, float* shift, int dtype,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* Autograd of the above: given dact = dL/d(out), overwrites y with dL/dy in place and ADDS the
+ * parameter gradients to dgamma / dbeta. */
+int odamd_bn_silu_backward(void* y_dy, int y_ld, const void* dact, int dact_ld, size_t npix, int channels,
+                           const float* scale, const float* shift, const float* mean, const float* invstd,
+                           float* dgamma, float* dbeta, int dtype, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
+/* dbias += sum over pixels of dy (head.output.bias, model/layer.py:232). */
+int odamd_bias_grad(const void* dy, int dy_ld, size_t npix, int channels, float* dbias, int dtype, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* Backward of MaxPool2d(2,2), of a stride-1 MaxPool2d(k, pad k/2) (float32 only) and of nearest
+ * Upsample x2.  All ADD into dx.  Ties go to the first maximum in row-major window order. */
+int odamd_maxpool2_backward(const void* x, int x_ld, const void* dy, int dy_ld, void* dx, int dx_ld, int batch, int h,
+                            int w, int c, int dtype, void* stream);
+int odamd_maxpool_s1_backward(const float* x, int x_ld, const float* dy, int dy_ld, float* dx, int dx_ld, int batch,
+                              int h, int w, int c, int ksize, void* stream);
+int odamd_upsample2_backward(const void* dy, int dy_ld, void* dx, int dx_ld, int batch, int h, int w, int c,
+                             int dtype, void* stream);
+
+/* Weight gradient of a convolution (autograd of cbs.conv / head.output): dw (cout, cin, k, k) float32
+ * in the reference's parameter layout, ADDED to (float atomics).  x: (B,H,W) NHWC input, dy: NHWC
+ * gradient of the raw output.  dtype float32 only in this version. */
+int odamd_conv_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int batch, int h, int w, int cin,
+                     int cout, int ksize, int stride, int dtype, void* stream);
+
+/* loss_class.__call__ (train_class.py:410-427) with focal objectness (:463-474), CIoU (:449-460)
+ * and BCE / soft-target cross-entropy class loss (:405-408): out4 = {loss, frame, confidence,
+ * class}; dpred = d loss / d pred.  screen[i], screen_img[i]: row and image of positive i; label:
+ * (n_pos, K).  n_pos == 0 gives frame = class = 1 without gradient, like the reference. */
+size_t odamd_loss_workspace_bytes(void);
+int odamd_detection_loss(const float* pred, float* dpred, const int* screen, const int* screen_img,
+                         const float* label, int batch, int rows, int kdim, int n_pos, float label_smooth,
+                         float* out4, void* workspace, size_t workspace_bytes, void* stream);
+
+/* torch.optim.Adam with coupled L2 (train_class.py:161-162) over flat float32 buffers, fused with
+ * model_ema.update (train_class.py:485-493) when ema != NULL.  step counts from 1; grad_scale
+ * multiplies the gradient first (1/world_size after a summing all-reduce).  Hyper-parameters are
+ * doubles: the reference forms 1-beta and 1-decay in Python doubles before they meet float32 data. */
+int odamd_adam_ema_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, size_t n,
+                        double lr, double beta1, double beta2, double eps, double weight_decay, int step,
+                        double ema_decay, double grad_scale, void* stream);
+int odamd_ema_update(float* ema, const float* src, size_t n, double decay, void* stream);
+
+/* Packs master float32 weights into the kernels' layouts for every convolution at once.
+ * table_dev: device array of n_entries descriptors of odamd_pack_desc_bytes() bytes each:
+ *   { const float* w; void* fwd; void* bwd; int cout, cin, k, cin_phys, cout_phys, n_seg;
+ *     int seg_off[8], seg_len[8]; }
+ * fwd: [cout][ky][kx][cin_phys]; bwd: [cin_phys][2-ky][2-kx][cout_phys] (data-gradient weights). */
+int odamd_pack_weights(const void* table_dev, int n_entries, int dtype, void* stream);
+size_t odamd_pack_desc_bytes(void);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,15 @@ class ConvDesc(C.Structure):
     _fields_ = [('x', c_void_p), ('w', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('y', c_void_p),
                 ('batch', c_int), ('h', c_int), ('w_in', c_int), ('cin', c_int), ('cout', c_int),
                 ('x_ld', c_int), ('y_ld', c_int), ('ksize', c_int), ('stride', c_int), ('act', c_int),
-                ('dtype', c_int), ('in_pool2', c_int), ('out_nchw_f32', c_int)]
+                ('dtype', c_int), ('in_pool2', c_int), ('out_nchw_f32', c_int), ('in_upzero2', c_int),
+                ('accumulate', c_int)]
+
+
+class PackDesc(C.Structure):
+    """One entry of the odamd_pack_weights table."""
+    _fields_ = [('w', c_void_p), ('fwd', c_void_p), ('bwd', c_void_p), ('cout', c_int), ('cin', c_int), ('k', c_int),
+                ('cin_phys', c_int), ('cout_phys', c_int), ('n_seg', c_int), ('seg_off', c_int * 8),
+                ('seg_len', c_int * 8)]
 
 
 # name -> (restype, argtypes); every symbol include/odamd.h declares must appear here.
@@ -56,11 +64,33 @@ SIGNATURES = {
     'odamd_iou_mask': (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p]),
     'odamd_conv_forward': (c_int, [C.POINTER(ConvDesc), c_void_p]),
     'odamd_conv_first_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                         c_int, c_int, c_int, c_void_p]),
+                                         c_int, c_int, c_int, c_int, c_void_p]),
     'odamd_maxpool2_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'odamd_spp_pool3_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_int, c_void_p]),
     'odamd_upsample2_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'odamd_bn_workspace_bytes': (c_size_t, [c_int]),
+    'odamd_bn_train_forward': (c_int, [c_void_p, c_int, c_void_p, c_int, c_size_t, c_int, c_void_p, c_void_p, c_float,
+                                       c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_size_t, c_void_p]),
+    'odamd_bn_silu_backward': (c_int, [c_void_p, c_int, c_void_p, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'odamd_bias_grad': (c_int, [c_void_p, c_int, c_size_t, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'odamd_maxpool2_backward': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, c_void_p]),
+    'odamd_maxpool_s1_backward': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                          c_int, c_void_p]),
+    'odamd_upsample2_backward': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'odamd_conv_wgrad': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                 c_int, c_int, c_void_p]),
+    'odamd_loss_workspace_bytes': (c_size_t, []),
+    'odamd_detection_loss': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                     c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'odamd_adam_ema_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, C.c_double, C.c_double,
+                                    C.c_double, C.c_double, C.c_double, c_int, C.c_double, C.c_double, c_void_p]),
+    'odamd_ema_update': (c_int, [c_void_p, c_void_p, c_size_t, C.c_double, c_void_p]),
+    'odamd_pack_weights': (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    'odamd_pack_desc_bytes': (c_size_t, []),
     'odamd_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'odamd_nhwc_to_nchw': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }

@@ -74,6 +74,8 @@ struct ConvP {
     int Hr, Wr;  // raw input size (differs from H, W only when pooling on load)
     int TH, TW, tiles_x, tiles_y, ncb, IH, IW;
     int act, pool, nchw;
+    int upz;    // input is zero-upsampled x2 on load (data gradient of a stride-2 convolution)
+    int accum;  // NHWC epilogue adds to the destination instead of overwriting it
     int nblocks;
 };
 
@@ -154,6 +156,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
         const int gy = iy0 + iy, gx = ix0 + ix;
         const bool inside = i < n_in && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         if (POOL) in_g[j] = inside ? ((2 * gy) * p.Wr + 2 * gx) * p.x_ld * ES + part * 16 : -1;
+        else if (p.upz) in_g[j] = (inside && !((gy | gx) & 1)) ? ((gy >> 1) * p.Wr + (gx >> 1)) * p.x_ld * ES + part * 16 : -1;
         else in_g[j] = inside ? (gy * p.W + gx) * p.x_ld * ES + part * 16 : -1;
     }
 #pragma unroll
@@ -164,7 +167,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
         const int co = co0 + row;
         w_g[j] = (row < 32 * CG && co < p.Cout) ? ((co * TAPS + tap) * p.Cin) * ES + part * 16 : -1;
     }
-    const char* xb = p.x + (size_t)b * (POOL ? (size_t)p.Hr * p.Wr : (size_t)p.H * p.W) * p.x_ld * ES;
+    const char* xb = p.x + (size_t)b * ((POOL || p.upz) ? (size_t)p.Hr * p.Wr : (size_t)p.H * p.W) * p.x_ld * ES;
 
     f32x16_t acc[PGW][CGW];
 #pragma unroll
@@ -300,6 +303,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
             }
             if (op >= 0 && c_lane < p.Cout) {
                 char* dst = p.y + ((ybase + op) * p.y_ld + c_lane) * ES;
+                if (p.accum) {
+                    if constexpr (DT == ODAMD_DTYPE_F32) {
+                        for (int e = 0; e < CPL; ++e)
+                            if (c_lane + e < p.Cout) v[e] += ((const float*)dst)[e];
+                    } else {
+                        for (int e = 0; e < CPL; ++e)
+                            if (c_lane + e < p.Cout) v[e] += bf16_to_f32(((const uint16_t*)dst)[e]);
+                    }
+                }
                 u32x4 pk;
                 if constexpr (DT == ODAMD_DTYPE_F32) {
                     pk = u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
@@ -332,7 +344,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
 template <int DT>
 __global__ void __launch_bounds__(256)
 conv_first_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ scale,
-                  const float* __restrict__ shift, char* __restrict__ y, int H, int W, int Cout, int y_ld) {
+                  const float* __restrict__ shift, char* __restrict__ y, int H, int W, int Cout, int y_ld, int act) {
     constexpr int T = 16;
     __shared__ float patch[3][T + 2][T + 3];
     const int b = blockIdx.z, oy0 = blockIdx.y * T, ox0 = blockIdx.x * T;
@@ -363,8 +375,8 @@ conv_first_kernel(const float* __restrict__ img, const float* __restrict__ w, co
             float a = 0.0f;
 #pragma unroll
             for (int k = 0; k < 27; ++k) a = fmaf(in[k], w[co * 27 + k], a);
-            a = a * scale[co] + shift[co];
-            o[e] = silu<DT>(a);
+            if (scale) a = a * scale[co] + shift[co];
+            o[e] = act ? silu<DT>(a) : a;
         }
         if (c0 + 8 <= Cout) {
             if constexpr (DT == ODAMD_DTYPE_F32) {
@@ -606,7 +618,11 @@ int odamd_conv_forward(const odamd_conv_desc* d, void* stream) {
     ConvP p = {};
     p.x = (const char*)d->x; p.w = (const char*)d->w; p.scale = d->scale; p.shift = d->shift; p.y = (char*)d->y;
     p.B = d->batch; p.Hr = d->h; p.Wr = d->w_in;
-    p.H = d->in_pool2 ? d->h / 2 : d->h; p.W = d->in_pool2 ? d->w_in / 2 : d->w_in;
+    p.H = d->in_pool2 ? d->h / 2 : (d->in_upzero2 ? d->h * 2 : d->h);
+    p.W = d->in_pool2 ? d->w_in / 2 : (d->in_upzero2 ? d->w_in * 2 : d->w_in);
+    p.upz = d->in_upzero2; p.accum = d->accumulate;
+    if (d->in_upzero2 && (d->in_pool2 || d->stride != 1)) return ODAMD_E_ARG;
+    if (d->accumulate && d->out_nchw_f32) return ODAMD_E_ARG;
     p.Cin = d->cin; p.Cout = d->cout; p.x_ld = d->x_ld; p.y_ld = d->y_ld;
     const int pad = (d->ksize - 1) / 2;
     p.Ho = (p.H + 2 * pad - d->ksize) / d->stride + 1;
@@ -622,17 +638,17 @@ int odamd_conv_forward(const odamd_conv_desc* d, void* stream) {
 }
 
 int odamd_conv_first_forward(const float* image, const float* w, const float* scale, const float* shift, void* y,
-                             int batch, int h, int w_in, int cout, int y_ld, int dtype, void* stream) {
-    if (!image || !w || !scale || !shift || !y || batch < 1 || h < 1 || w_in < 1 || cout < 1) return ODAMD_E_ARG;
+                             int batch, int h, int w_in, int cout, int y_ld, int act, int dtype, void* stream) {
+    if (!image || !w || !y || batch < 1 || h < 1 || w_in < 1 || cout < 1 || (!scale != !shift)) return ODAMD_E_ARG;
     if (dtype != ODAMD_DTYPE_F32 && dtype != ODAMD_DTYPE_BF16) return ODAMD_E_ARG;
     const int es = dtype == ODAMD_DTYPE_F32 ? 4 : 2;
     if (y_ld < cout) return ODAMD_E_SHAPE;
     if (((uintptr_t)y & 15) || (y_ld * es) % 16) return ODAMD_E_ALIGN;
     dim3 grid((w_in + 15) / 16, (h + 15) / 16, batch);
     if (dtype == ODAMD_DTYPE_F32)
-        conv_first_kernel<ODAMD_DTYPE_F32><<<grid, 256, 0, (hipStream_t)stream>>>(image, w, scale, shift, (char*)y, h, w_in, cout, y_ld);
+        conv_first_kernel<ODAMD_DTYPE_F32><<<grid, 256, 0, (hipStream_t)stream>>>(image, w, scale, shift, (char*)y, h, w_in, cout, y_ld, act);
     else
-        conv_first_kernel<ODAMD_DTYPE_BF16><<<grid, 256, 0, (hipStream_t)stream>>>(image, w, scale, shift, (char*)y, h, w_in, cout, y_ld);
+        conv_first_kernel<ODAMD_DTYPE_BF16><<<grid, 256, 0, (hipStream_t)stream>>>(image, w, scale, shift, (char*)y, h, w_in, cout, y_ld, act);
     return (int)hipGetLastError();
 }
 

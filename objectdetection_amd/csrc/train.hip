@@ -1,0 +1,839 @@
+// Training-step kernels for gfx950: train-mode BatchNorm + SiLU (forward and backward), pooling /
+// upsample backward, convolution weight gradient on the matrix cores, detection loss
+// (forward + gradient), fused Adam + EMA, weight packing.
+//
+// Layout conventions are those of conv.hip: NHWC activations with pixel stride `ld`, 16-byte
+// channel vectors.  All reductions over pixels are done as per-workgroup partials in double
+// followed by a tiny finalize kernel, so statistics and their gradients are bitwise reproducible
+// run to run; only the weight gradient uses float atomics (one add per workgroup and element).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+#include "odamd.h"
+
+namespace {
+
+constexpr int RED_MAX_BLOCKS = 512;
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + expf(-z)); }
+// d silu / dz = s (1 + z (1 - s)),  s = sigmoid(z)
+__device__ __forceinline__ float silu_grad(float z) {
+    const float s = 1.0f / (1.0f + expf(-z));
+    return s * (1.0f + z * (1.0f - s));
+}
+
+template <int DT> struct Vec;
+template <> struct Vec<ODAMD_DTYPE_F32> {
+    static constexpr int N = 4, ES = 4;
+    static __device__ __forceinline__ void load(const char* p, float* v) {
+        const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(char* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec<ODAMD_DTYPE_BF16> {
+    static constexpr int N = 8, ES = 2;
+    static __device__ __forceinline__ void load(const char* p, float* v) {
+        const uint4 t = *(const uint4*)p;
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u); }
+    }
+    static __device__ __forceinline__ void store(char* p, const float* v) {
+        uint4 t;
+        t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        t.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+        t.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+        *(uint4*)p = t;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Per-channel reductions over pixels.  Workgroup = vecs x rows threads: thread (v, r) owns the
+// channels of 16-byte vector v and walks pixels r, r+rows, ... of the workgroup's pixel range.
+// MODE 0: sum(y), sum(y^2)                                       (BN statistics)
+// MODE 1: sum(dz), sum(dz * xhat), dz = dact * silu'(z)          (BN + SiLU backward)
+// MODE 2: sum(y)                                                 (bias gradient)
+// Partials land in part[block][2][C] as doubles.
+// ------------------------------------------------------------------------------------------
+template <int DT, int MODE>
+__global__ void __launch_bounds__(256)
+channel_reduce_kernel(const char* __restrict__ y, int y_ld, const char* __restrict__ dact, int d_ld, size_t npix, int C,
+                      int vecs, int rows, const float* __restrict__ scale, const float* __restrict__ shift,
+                      const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ part) {
+    constexpr int N = Vec<DT>::N, ES = Vec<DT>::ES;
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [rows][vecs][2][N]
+    const int v = threadIdx.x % vecs, r = threadIdx.x / vecs;
+    const size_t per = (npix + gridDim.x - 1) / gridDim.x;
+    const size_t p0 = (size_t)blockIdx.x * per, p1 = min(npix, p0 + per);
+    float s0[N], s1[N], sc[N], sh[N], mu[N], is[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        s0[e] = 0.f; s1[e] = 0.f;
+        const int c = v * N + e;
+        if (MODE == 1) { sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c]; }
+    }
+    for (size_t p = p0 + r; p < p1; p += rows) {
+        float a[N];
+        Vec<DT>::load(y + (p * y_ld) * ES + v * 16, a);
+        if (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) { s0[e] += a[e]; s1[e] += a[e] * a[e]; }
+        } else if (MODE == 1) {
+            float g[N];
+            Vec<DT>::load(dact + (p * d_ld) * ES + v * 16, g);
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                const float dz = g[e] * silu_grad(a[e] * sc[e] + sh[e]);
+                s0[e] += dz;
+                s1[e] += dz * ((a[e] - mu[e]) * is[e]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < N; ++e) s0[e] += a[e];
+        }
+    }
+    float* mine = red + ((size_t)(r * vecs + v) * 2) * N;
+#pragma unroll
+    for (int e = 0; e < N; ++e) { mine[e] = s0[e]; mine[N + e] = s1[e]; }
+    __syncthreads();
+    if (r == 0) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            double a0 = 0.0, a1 = 0.0;
+            for (int rr = 0; rr < rows; ++rr) {
+                const float* o = red + ((size_t)(rr * vecs + v) * 2) * N;
+                a0 += o[e]; a1 += o[N + e];
+            }
+            part[((size_t)blockIdx.x * 2 + 0) * C + v * N + e] = a0;
+            part[((size_t)blockIdx.x * 2 + 1) * C + v * N + e] = a1;
+        }
+    }
+}
+
+// BN statistics finalize (model/layer.py:9,14 in train mode): batch mean / biased variance, running
+// buffers updated with momentum and the unbiased variance, affine folded to (scale, shift).
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ part, int nblk, int C, double npix, const float* gamma,
+                                         const float* beta, float eps, float momentum, float* running_mean,
+                                         float* running_var, float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
+    const double m = s / npix;
+    double var = q / npix - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)m;
+    invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)m * sc;
+    if (running_mean) {
+        const double unb = npix > 1.0 ? var * npix / (npix - 1.0) : var;
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+// Backward finalize: dgamma, dbeta (accumulated into the parameter gradients) and the two
+// per-channel means the apply pass needs.
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, int C, double npix, float* dgamma,
+                                       float* dbeta, float* mean_dz, float* mean_dzx) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
+    dbeta[c] += (float)s;
+    dgamma[c] += (float)q;
+    mean_dz[c] = (float)(s / npix);
+    mean_dzx[c] = (float)(q / npix);
+}
+
+__global__ void bias_grad_finalize_kernel(const double* __restrict__ part, int nblk, int C, float* dbias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += part[((size_t)b * 2) * C + c];
+    dbias[c] += (float)s;
+}
+
+// act = silu(y*scale + shift), written at a channel offset of a wider buffer.
+template <int DT>
+__global__ void __launch_bounds__(256)
+bn_apply_silu_kernel(const char* __restrict__ y, int y_ld, char* __restrict__ out, int o_ld, size_t npix, int vecs,
+                     const float* __restrict__ scale, const float* __restrict__ shift) {
+    constexpr int N = Vec<DT>::N, ES = Vec<DT>::ES;
+    const size_t n = npix * vecs;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int v = i % vecs;
+        const size_t p = i / vecs;
+        float a[N];
+        Vec<DT>::load(y + (p * y_ld) * ES + v * 16, a);
+#pragma unroll
+        for (int e = 0; e < N; ++e) a[e] = silu_f(a[e] * scale[v * N + e] + shift[v * N + e]);
+        Vec<DT>::store(out + (p * o_ld) * ES + v * 16, a);
+    }
+}
+
+// dy = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat)), written over y in place.
+template <int DT>
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_kernel(char* __restrict__ y, int y_ld, const char* __restrict__ dact, int d_ld, size_t npix, int vecs,
+                    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+                    const float* __restrict__ invstd, const float* __restrict__ mean_dz,
+                    const float* __restrict__ mean_dzx) {
+    constexpr int N = Vec<DT>::N, ES = Vec<DT>::ES;
+    const size_t n = npix * vecs;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int v = i % vecs;
+        const size_t p = i / vecs;
+        float a[N], g[N];
+        Vec<DT>::load(y + (p * y_ld) * ES + v * 16, a);
+        Vec<DT>::load(dact + (p * d_ld) * ES + v * 16, g);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const int c = v * N + e;
+            const float dz = g[e] * silu_grad(a[e] * scale[c] + shift[c]);
+            const float xh = (a[e] - mean[c]) * invstd[c];
+            a[e] = scale[c] * (dz - mean_dz[c] - xh * mean_dzx[c]);   // scale = gamma * invstd
+        }
+        Vec<DT>::store(y + (p * y_ld) * ES + v * 16, a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// pooling / upsample backward (gradients are accumulated: dx += ...)
+// ------------------------------------------------------------------------------------------
+// MaxPool2d(2,2): gradient goes to the first maximum in row-major window order (torch's argmax).
+template <int DT>
+__global__ void __launch_bounds__(256)
+maxpool2_bwd_kernel(const char* __restrict__ x, int x_ld, const char* __restrict__ dy, int dy_ld, char* __restrict__ dx,
+                    int dx_ld, int B, int H, int W, int vecs) {
+    constexpr int N = Vec<DT>::N, ES = Vec<DT>::ES;
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t n = (size_t)B * Ho * Wo * vecs;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int v = i % vecs;
+        size_t pix = i / vecs;
+        const int ox = pix % Wo; pix /= Wo;
+        const int oy = pix % Ho;
+        const int b = pix / Ho;
+        float g[N], in[4][N], acc[4][N];
+        Vec<DT>::load(dy + ((((size_t)b * Ho + oy) * Wo + ox) * dy_ld) * ES + v * 16, g);
+        size_t off[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            off[q] = (((size_t)b * H + 2 * oy + (q >> 1)) * W + 2 * ox + (q & 1));
+            Vec<DT>::load(x + (off[q] * x_ld) * ES + v * 16, in[q]);
+            Vec<DT>::load(dx + (off[q] * dx_ld) * ES + v * 16, acc[q]);
+        }
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            int best = 0;
+            float m = in[0][e];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (in[q][e] > m) { m = in[q][e]; best = q; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q][e] += (q == best) ? g[e] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Vec<DT>::store(dx + (off[q] * dx_ld) * ES + v * 16, acc[q]);
+    }
+}
+
+// Stride-1 max pool k (pad k/2): one thread per output window and channel finds the first maximum
+// in row-major order and adds the window's gradient there.  float32 gradients only (atomics).
+__global__ void __launch_bounds__(256)
+maxpool_s1_bwd_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ dy, int dy_ld,
+                      float* __restrict__ dx, int dx_ld, int B, int H, int W, int C, int k) {
+    const size_t n = (size_t)B * H * W * C;
+    const int rad = k / 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int c = i % C;
+        size_t pix = i / C;
+        const int ox = pix % W; pix /= W;
+        const int oy = pix % H;
+        const int b = pix / H;
+        float m = -INFINITY;
+        size_t arg = 0;
+        for (int gy = max(oy - rad, 0); gy <= min(oy + rad, H - 1); ++gy)
+            for (int gx = max(ox - rad, 0); gx <= min(ox + rad, W - 1); ++gx) {
+                const size_t o = ((size_t)b * H + gy) * W + gx;
+                const float t = x[o * x_ld + c];
+                if (t > m) { m = t; arg = o; }
+            }
+        atomicAdd(&dx[arg * dx_ld + c], dy[(((size_t)b * H + oy) * W + ox) * dy_ld + c]);
+    }
+}
+
+// nearest x2 upsample: dx(y, x) += sum of the 2x2 block of dy.
+template <int DT>
+__global__ void __launch_bounds__(256)
+upsample2_bwd_kernel(const char* __restrict__ dy, int dy_ld, char* __restrict__ dx, int dx_ld, int B, int H, int W, int vecs) {
+    constexpr int N = Vec<DT>::N, ES = Vec<DT>::ES;
+    const size_t n = (size_t)B * H * W * vecs;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int v = i % vecs;
+        size_t pix = i / vecs;
+        const int ix = pix % W; pix /= W;
+        const int iy = pix % H;
+        const int b = pix / H;
+        float acc[N], g[N];
+        char* d = dx + ((((size_t)b * H + iy) * W + ix) * dx_ld) * ES + v * 16;
+        Vec<DT>::load(d, acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            Vec<DT>::load(dy + ((((size_t)b * 2 * H + 2 * iy + (q >> 1)) * 2 * W + 2 * ix + (q & 1)) * dy_ld) * ES + v * 16, g);
+#pragma unroll
+            for (int e = 0; e < N; ++e) acc[e] += g[e];
+        }
+        Vec<DT>::store(d, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Convolution weight gradient, float32 on v_mfma_f32_32x32x2_f32:
+//   dW[co][ci][ky][kx] = sum_pixels dY[pixel][co] * X[pixel*stride - pad + (ky,kx)][ci]
+// GEMM view: M = 32 output channels, N = 32 input channels (per tap), K = pixels.  A workgroup owns
+// one (co block, ci block) pair and a range of pixel patches; per patch it stages the dY patch
+// [pixels][32 co] and the X halo patch [pixels][32 ci] in LDS (rows of 128 bytes: a fragment read
+// is 32 consecutive floats, conflict free), accumulates in registers across all its patches and
+// finishes with one atomic add per element.  KS == 3: wave w takes taps w, w+4, w+8 over all
+// pixels of the patch; KS == 1: the four waves split the pixels.
+// ------------------------------------------------------------------------------------------
+struct WgradP {
+    const float* x; const float* dy; float* dw;
+    int B, H, W, Ho, Wo, Cin, Cout, x_ld, dy_ld;
+    int TH, TW, tiles_x, tiles_y, IH, IW, nsplit, ntiles, ncin;
+};
+
+template <int KS, int ST>
+__global__ void __launch_bounds__(256) conv_wgrad_f32_kernel(WgradP p) {
+    constexpr int TAPS = KS * KS, PAD = (KS - 1) / 2;
+    constexpr int NACC = KS == 1 ? 1 : 3;
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    const int npix = p.TH * p.TW;
+    float* dyl = wl;                                  // [npix][32]
+    float* xl = wl + (size_t)npix * 32;               // [IH*IW][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, kk = lane >> 5;
+    const int cb = blockIdx.y / p.ncin, ib = blockIdx.y % p.ncin;
+    const int co0 = cb * 32, ci0 = ib * 32;
+    const int nco = min(32, p.Cout - co0), nci = min(32, p.Cin - ci0);
+
+    f32x16_t acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][e] = 0.0f;
+
+    for (int t = blockIdx.x; t < p.ntiles; t += p.nsplit) {
+        const int b = t / (p.tiles_x * p.tiles_y), tt = t % (p.tiles_x * p.tiles_y);
+        const int oy0 = (tt / p.tiles_x) * p.TH, ox0 = (tt % p.tiles_x) * p.TW;
+        __syncthreads();
+        // dY patch: 8 float4 per pixel
+        for (int i = tid; i < npix * 8; i += 256) {
+            const int pix = i >> 3, part = i & 7;
+            const int oy = oy0 + pix / p.TW, ox = ox0 + pix % p.TW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oy < p.Ho && ox < p.Wo) {
+                const float* s = p.dy + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0 + part * 4;
+                if (part * 4 + 4 <= nco) v = *(const float4*)s;
+                else { float* f = (float*)&v; for (int e = 0; part * 4 + e < nco; ++e) f[e] = s[e]; }
+            }
+            *(float4*)(dyl + pix * 32 + part * 4) = v;
+        }
+        // X halo patch
+        const int iy0 = oy0 * ST - PAD, ix0 = ox0 * ST - PAD;
+        for (int i = tid; i < p.IH * p.IW * 8; i += 256) {
+            const int pix = i >> 3, part = i & 7;
+            const int gy = iy0 + pix / p.IW, gx = ix0 + pix % p.IW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                const float* s = p.x + (((size_t)b * p.H + gy) * p.W + gx) * p.x_ld + ci0 + part * 4;
+                if (part * 4 + 4 <= nci) v = *(const float4*)s;
+                else { float* f = (float*)&v; for (int e = 0; part * 4 + e < nci; ++e) f[e] = s[e]; }
+            }
+            *(float4*)(xl + pix * 32 + part * 4) = v;
+        }
+        __syncthreads();
+        if (KS == 1) {
+            const int q0 = wave * (npix / 4), q1 = q0 + npix / 4;
+            for (int q = q0 + kk; q < q1; q += 2) {
+                const int ty = q / p.TW, tx = q - ty * p.TW;
+                const float a = dyl[q * 32 + col];
+                const float bv = xl[((ty * ST) * p.IW + tx * ST) * 32 + col];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[0], 0, 0, 0);
+            }
+        } else {
+            for (int q = kk; q < npix; q += 2) {
+                const int ty = q / p.TW, tx = q - ty * p.TW;
+                const float a = dyl[q * 32 + col];
+                const int base = ((ty * ST) * p.IW + tx * ST) * 32 + col;
+#pragma unroll
+                for (int j = 0; j < NACC; ++j) {
+                    const int tap = wave + 4 * j;
+                    if (tap < TAPS) {
+                        const float bv = xl[base + ((tap / KS) * p.IW + (tap % KS)) * 32];
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // D[row = co][col = ci]: lane holds col = lane&31, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) {
+        const int tap = KS == 1 ? 0 : wave + 4 * j;
+        if (tap >= TAPS) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = (e & 3) + 8 * (e >> 2) + 4 * kk, ci = col;
+            if (co < nco && ci < nci)
+                atomicAdd(&p.dw[((size_t)(co0 + co) * p.Cin + ci0 + ci) * TAPS + tap], acc[j][e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Detection loss (train_class.py:410-474): forward value and gradient wrt the decoded predictions.
+// ------------------------------------------------------------------------------------------
+// value + 4 partial derivatives (wrt predicted cx, cy, w, h): forward-mode differentiation keeps
+// the CIoU backward an exact transcription of the forward formula.
+struct D4 {
+    float v, d[4];
+};
+__device__ __forceinline__ D4 dconst(float v) { return {v, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ D4 dvar(float v, int i) { D4 r = dconst(v); r.d[i] = 1.f; return r; }
+__device__ __forceinline__ D4 operator+(D4 a, D4 b) { D4 r; r.v = a.v + b.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ D4 operator-(D4 a, D4 b) { D4 r; r.v = a.v - b.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ D4 operator*(D4 a, D4 b) { D4 r; r.v = a.v * b.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ D4 operator/(D4 a, D4 b) {
+    D4 r; r.v = a.v / b.v;
+    for (int i = 0; i < 4; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v;
+    return r;
+}
+__device__ __forceinline__ D4 dscale(D4 a, float s) { D4 r; r.v = a.v * s; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * s; return r; }
+__device__ __forceinline__ D4 dmax(D4 a, D4 b) { return a.v >= b.v ? a : b; }
+__device__ __forceinline__ D4 dmin(D4 a, D4 b) { return a.v <= b.v ? a : b; }
+__device__ __forceinline__ D4 dclamp0(D4 a) { return a.v > 0.f ? a : dconst(0.f); }
+__device__ __forceinline__ D4 datan(D4 a) { D4 r; r.v = atanf(a.v); const float g = 1.f / (1.f + a.v * a.v); for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * g; return r; }
+
+// CIoU of train_class.py:449-460 for one (prediction, label) pair; returns value and d/d(cx,cy,w,h).
+__device__ D4 ciou_d4(const float* pr, const float* lb) {
+    const D4 cx = dvar(pr[0], 0), cy = dvar(pr[1], 1), w = dvar(pr[2], 2), h = dvar(pr[3], 3);
+    const D4 px = cx - dscale(w, 0.5f), py = cy - dscale(h, 0.5f);
+    const float lw = lb[2], lh = lb[3], lx = lb[0] - lw / 2, ly = lb[1] - lh / 2;
+    const D4 Lx = dconst(lx), Ly = dconst(ly), Lx2 = dconst(lx + lw), Ly2 = dconst(ly + lh);
+    const D4 x1 = dmax(px, Lx), y1 = dmax(py, Ly), x2 = dmin(px + w, Lx2), y2 = dmin(py + h, Ly2);
+    const D4 inter = dclamp0(x2 - x1) * dclamp0(y2 - y1);
+    const D4 uni = w * h + dconst(lw * lh) - inter;
+    const D4 iou = inter / uni;
+    const D4 ex1 = dmin(px, Lx), ey1 = dmin(py, Ly), ex2 = dmax(px + w, Lx2), ey2 = dmax(py + h, Ly2);
+    const D4 dxl = px - Lx, dyl = py - Ly, ew = ex2 - ex1, eh = ey2 - ey1;
+    const D4 dist = (dxl * dxl + dyl * dyl) / (ew * ew + eh * eh);
+    const D4 da = dconst(atanf(lw / lh)) - datan(w / h);
+    const D4 v = dscale(da * da, 4.0f / (3.1415926f * 3.1415926f));
+    const float alpha = v.v / (v.v + 1.0f - iou.v + 0.00001f);   // no gradient through alpha
+    return iou - dist - dscale(v, alpha);
+}
+
+struct LossP {
+    const float* pred;        // (B, R, K)
+    float* dpred;             // (B, R, K), zero on entry
+    const int* screen;        // (P) row index within its image
+    const int* screen_img;    // (P) image index
+    const float* label;       // (P, K)
+    int B, R, K, P;
+    float smooth;
+    double* part;             // [0..nblk) confidence partials, then [nblk..2 nblk) frame, [2 nblk..3 nblk) class
+    int nblk;
+    float* out;               // (4) loss, frame, confidence, class
+};
+
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double r = sm[0];
+    __syncthreads();
+    return r;
+}
+
+// Marks the positive rows: dpred[b][r][4] = 1 (a flag consumed and overwritten by the next kernel).
+__global__ void loss_mark_kernel(LossP p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p.P) p.dpred[((size_t)p.screen_img[i] * p.R + p.screen[i]) * p.K + 4] = 1.0f;
+}
+
+// Focal objectness loss over every row (train_class.py:470-474, alpha = 0.5, gamma = 2, x100).
+__global__ void __launch_bounds__(256) loss_conf_kernel(LossP p) {
+    __shared__ double sm[256];
+    const size_t n = (size_t)p.B * p.R;
+    double acc = 0.0;
+    const float gscale = 100.0f / (float)n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float x = p.pred[i * p.K + 4];
+        const float y = p.dpred[i * p.K + 4] != 0.0f ? 1.0f - p.smooth : p.smooth;
+        const float bce = fmaxf(x, 0.0f) - x * y + log1pf(expf(-fabsf(x)));
+        const float e = expf(-bce), om = 1.0f - e;
+        const float a = 0.5f * y + 0.5f * (1.0f - y);
+        acc += (double)(a * om * om * bce);
+        // d/dx: a * (2 om e bce + om^2) * (sigmoid(x) - y)
+        const float sg = 1.0f / (1.0f + expf(-x));
+        p.dpred[i * p.K + 4] = gscale * a * (2.0f * om * e * bce + om * om) * (sg - y);
+    }
+    const double s = block_sum(acc, sm);
+    if (threadIdx.x == 0) p.part[blockIdx.x] = s;
+}
+
+// Box (CIoU) and class terms over the positive rows (train_class.py:424-425).
+__global__ void __launch_bounds__(256) loss_pos_kernel(LossP p) {
+    __shared__ double sm[256];
+    double fa = 0.0, ca = 0.0;
+    const int C = p.K - 5;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.P; i += gridDim.x * 256) {
+        const size_t row = ((size_t)p.screen_img[i] * p.R + p.screen[i]) * p.K;
+        const float* pr = p.pred + row;
+        const float* lb = p.label + (size_t)i * p.K;
+        float* g = p.dpred + row;
+        const D4 c = ciou_d4(pr, lb);
+        fa += (double)c.v;
+        for (int k = 0; k < 4; ++k) g[k] = -c.d[k] / (float)p.P;      // frame = 1 - mean(ciou)
+        if (C == 1) {                                                  // BCEWithLogitsLoss, mean over P
+            const float x = pr[5], y = lb[5];
+            ca += (double)(fmaxf(x, 0.0f) - x * y + log1pf(expf(-fabsf(x))));
+            g[5] = (1.0f / (1.0f + expf(-x)) - y) / (float)p.P;
+        } else {                                                       // CrossEntropyLoss with soft targets
+            float m = pr[5];
+            for (int k = 1; k < C; ++k) m = fmaxf(m, pr[5 + k]);
+            float se = 0.0f, ts = 0.0f;
+            for (int k = 0; k < C; ++k) { se += expf(pr[5 + k] - m); ts += lb[5 + k]; }
+            const float lse = m + logf(se);
+            float l = 0.0f;
+            for (int k = 0; k < C; ++k) {
+                l -= lb[5 + k] * (pr[5 + k] - lse);
+                g[5 + k] = (expf(pr[5 + k] - lse) * ts - lb[5 + k]) / (float)p.P;
+            }
+            ca += (double)l;
+        }
+    }
+    const double f = block_sum(fa, sm);
+    const double c = block_sum(ca, sm);
+    if (threadIdx.x == 0) { p.part[p.nblk + blockIdx.x] = f; p.part[2 * p.nblk + blockIdx.x] = c; }
+}
+
+__global__ void loss_finalize_kernel(LossP p, int nconf, int npos) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double c = 0.0, f = 0.0, k = 0.0;
+    for (int i = 0; i < nconf; ++i) c += p.part[i];
+    for (int i = 0; i < npos; ++i) { f += p.part[p.nblk + i]; k += p.part[2 * p.nblk + i]; }
+    const float conf = (float)(100.0 * c / ((double)p.B * p.R));
+    float frame = 1.0f, cls = 1.0f;                                     // no positives: constants
+    if (p.P > 0) { frame = (float)(1.0 - f / p.P); cls = (float)(k / p.P); }
+    p.out[0] = frame + conf + cls;
+    p.out[1] = frame;
+    p.out[2] = conf;
+    p.out[3] = cls;
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam (coupled L2, train_class.py:161-162) + EMA (train_class.py:485-493) over flat buffers.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                float* __restrict__ ema, size_t n, float step_size, float om_beta1, float beta2, float om_beta2,
+                float bc2_sqrt, float eps, float wd, float ema_decay, float om_ema_decay, float grad_scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float w = p[i];
+        const float gr = g[i] * grad_scale + wd * w;
+        float mm = m[i];
+        mm = mm + om_beta1 * (gr - mm);                                 // exp_avg.lerp_(grad, 1 - beta1)
+        const float vv = beta2 * v[i] + om_beta2 * (gr * gr);
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        w = w - step_size * (mm / denom);
+        m[i] = mm;
+        v[i] = vv;
+        p[i] = w;
+        if (ema) ema[i] = ema_decay * ema[i] + om_ema_decay * w;
+    }
+}
+
+__global__ void __launch_bounds__(256) ema_only_kernel(float* __restrict__ ema, const float* __restrict__ src, size_t n, float d, float omd) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        ema[i] = d * ema[i] + omd * src[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight packing: float32 (cout, cin, k, k) master weights -> forward layout [cout][ky][kx][cin_phys]
+// and data-gradient layout [cin][ky'][kx'][cout_phys] with the taps flipped, in the compute dtype.
+// One launch covers every convolution of the network through a descriptor table.
+// ------------------------------------------------------------------------------------------
+struct PackDesc {
+    const float* w;       // source
+    void* fwd;            // destination, forward layout (may be null)
+    void* bwd;            // destination, data-gradient layout (may be null)
+    int cout, cin, k, cin_phys, cout_phys;
+    int n_seg;            // cin is spread over segments of the consumer's input buffer
+    int seg_off[8], seg_len[8];
+};
+
+__global__ void __launch_bounds__(256) pack_weights_kernel(const PackDesc* __restrict__ table, int dtype) {
+    const PackDesc d = table[blockIdx.y];
+    const int kk = d.k * d.k;
+    const size_t n = (size_t)d.cout * d.cin * kk;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int t = i % kk;
+        const int ci = (i / kk) % d.cin;
+        const int co = i / ((size_t)kk * d.cin);
+        const float v = d.w[i];
+        int phys = ci, rem = ci;                     // logical -> physical input channel
+        for (int s = 0; s < d.n_seg; ++s) {
+            if (rem < d.seg_len[s]) { phys = d.seg_off[s] + rem; break; }
+            rem -= d.seg_len[s];
+        }
+        if (d.fwd) {
+            const size_t o = ((size_t)co * kk + t) * d.cin_phys + phys;
+            if (dtype == ODAMD_DTYPE_F32) ((float*)d.fwd)[o] = v; else ((uint16_t*)d.fwd)[o] = f32_to_bf16(v);
+        }
+        if (d.bwd) {
+            const size_t o = ((size_t)phys * kk + (kk - 1 - t)) * d.cout_phys + co;
+            if (dtype == ODAMD_DTYPE_F32) ((float*)d.bwd)[o] = v; else ((uint16_t*)d.bwd)[o] = f32_to_bf16(v);
+        }
+    }
+}
+
+int red_geometry(int C, int dtype, int* vecs, int* rows) {
+    const int per = dtype == ODAMD_DTYPE_F32 ? 4 : 8;
+    if (C % per) return ODAMD_E_ALIGN;
+    *vecs = C / per;
+    if (*vecs > 256) return ODAMD_E_SHAPE;
+    *rows = 256 / *vecs;
+    return ODAMD_OK;
+}
+
+int red_blocks(size_t npix, int rows) {
+    size_t b = (npix + (size_t)rows * 16 - 1) / ((size_t)rows * 16);
+    if (b > RED_MAX_BLOCKS) b = RED_MAX_BLOCKS;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+int ew_grid(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t odamd_bn_workspace_bytes(int channels) { return (size_t)RED_MAX_BLOCKS * 2 * channels * sizeof(double); }
+
+int odamd_bn_train_forward(const void* y, int y_ld, void* out, int out_ld, size_t npix, int channels, const float* gamma,
+                           const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                           float* mean, float* invstd, float* scale, float* shift, int dtype, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    if (!y || !out || !gamma || !beta || !mean || !invstd || !scale || !shift || !workspace || npix < 1) return ODAMD_E_ARG;
+    if (dtype != ODAMD_DTYPE_F32 && dtype != ODAMD_DTYPE_BF16) return ODAMD_E_ARG;
+    if (workspace_bytes < odamd_bn_workspace_bytes(channels)) return ODAMD_E_WORKSPACE;
+    int vecs, rows, rc;
+    if ((rc = red_geometry(channels, dtype, &vecs, &rows))) return rc;
+    if (((uintptr_t)y & 15) || ((uintptr_t)out & 15)) return ODAMD_E_ALIGN;
+    const int nblk = red_blocks(npix, rows);
+    hipStream_t st = (hipStream_t)stream;
+    const int per = dtype == ODAMD_DTYPE_F32 ? 4 : 8;
+    const size_t lds = (size_t)rows * vecs * 2 * per * sizeof(float);
+    double* part = (double*)workspace;
+    if (dtype == ODAMD_DTYPE_F32)
+        channel_reduce_kernel<ODAMD_DTYPE_F32, 0><<<nblk, vecs * rows, lds, st>>>((const char*)y, y_ld, nullptr, 0, npix, channels, vecs, rows, nullptr, nullptr, nullptr, nullptr, part);
+    else
+        channel_reduce_kernel<ODAMD_DTYPE_BF16, 0><<<nblk, vecs * rows, lds, st>>>((const char*)y, y_ld, nullptr, 0, npix, channels, vecs, rows, nullptr, nullptr, nullptr, nullptr, part);
+    bn_stats_finalize_kernel<<<(channels + 63) / 64, 64, 0, st>>>(part, nblk, channels, (double)npix, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+    if (dtype == ODAMD_DTYPE_F32)
+        bn_apply_silu_kernel<ODAMD_DTYPE_F32><<<ew_grid(npix * vecs), 256, 0, st>>>((const char*)y, y_ld, (char*)out, out_ld, npix, vecs, scale, shift);
+    else
+        bn_apply_silu_kernel<ODAMD_DTYPE_BF16><<<ew_grid(npix * vecs), 256, 0, st>>>((const char*)y, y_ld, (char*)out, out_ld, npix, vecs, scale, shift);
+    return (int)hipGetLastError();
+}
+
+int odamd_bn_silu_backward(void* y_dy, int y_ld, const void* dact, int dact_ld, size_t npix, int channels,
+                           const float* scale, const float* shift, const float* mean, const float* invstd, float* dgamma,
+                           float* dbeta, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!y_dy || !dact || !scale || !shift || !mean || !invstd || !dgamma || !dbeta || !workspace || npix < 1) return ODAMD_E_ARG;
+    if (dtype != ODAMD_DTYPE_F32 && dtype != ODAMD_DTYPE_BF16) return ODAMD_E_ARG;
+    if (workspace_bytes < odamd_bn_workspace_bytes(channels) + 2 * channels * sizeof(float)) return ODAMD_E_WORKSPACE;
+    int vecs, rows, rc;
+    if ((rc = red_geometry(channels, dtype, &vecs, &rows))) return rc;
+    const int nblk = red_blocks(npix, rows);
+    hipStream_t st = (hipStream_t)stream;
+    const int per = dtype == ODAMD_DTYPE_F32 ? 4 : 8;
+    const size_t lds = (size_t)rows * vecs * 2 * per * sizeof(float);
+    double* part = (double*)workspace;
+    float* mean_dz = (float*)((char*)workspace + odamd_bn_workspace_bytes(channels));
+    float* mean_dzx = mean_dz + channels;
+    if (dtype == ODAMD_DTYPE_F32)
+        channel_reduce_kernel<ODAMD_DTYPE_F32, 1><<<nblk, vecs * rows, lds, st>>>((const char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, channels, vecs, rows, scale, shift, mean, invstd, part);
+    else
+        channel_reduce_kernel<ODAMD_DTYPE_BF16, 1><<<nblk, vecs * rows, lds, st>>>((const char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, channels, vecs, rows, scale, shift, mean, invstd, part);
+    bn_bwd_finalize_kernel<<<(channels + 63) / 64, 64, 0, st>>>(part, nblk, channels, (double)npix, dgamma, dbeta, mean_dz, mean_dzx);
+    if (dtype == ODAMD_DTYPE_F32)
+        bn_bwd_apply_kernel<ODAMD_DTYPE_F32><<<ew_grid(npix * vecs), 256, 0, st>>>((char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, vecs, scale, shift, mean, invstd, mean_dz, mean_dzx);
+    else
+        bn_bwd_apply_kernel<ODAMD_DTYPE_BF16><<<ew_grid(npix * vecs), 256, 0, st>>>((char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, vecs, scale, shift, mean, invstd, mean_dz, mean_dzx);
+    return (int)hipGetLastError();
+}
+
+int odamd_bias_grad(const void* dy, int dy_ld, size_t npix, int channels, float* dbias, int dtype, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+    if (!dy || !dbias || !workspace || npix < 1) return ODAMD_E_ARG;
+    if (workspace_bytes < odamd_bn_workspace_bytes(channels)) return ODAMD_E_WORKSPACE;
+    int vecs, rows, rc;
+    if ((rc = red_geometry(channels, dtype, &vecs, &rows))) return rc;
+    const int nblk = red_blocks(npix, rows);
+    hipStream_t st = (hipStream_t)stream;
+    const int per = dtype == ODAMD_DTYPE_F32 ? 4 : 8;
+    const size_t lds = (size_t)rows * vecs * 2 * per * sizeof(float);
+    double* part = (double*)workspace;
+    if (dtype == ODAMD_DTYPE_F32)
+        channel_reduce_kernel<ODAMD_DTYPE_F32, 2><<<nblk, vecs * rows, lds, st>>>((const char*)dy, dy_ld, nullptr, 0, npix, channels, vecs, rows, nullptr, nullptr, nullptr, nullptr, part);
+    else if (dtype == ODAMD_DTYPE_BF16)
+        channel_reduce_kernel<ODAMD_DTYPE_BF16, 2><<<nblk, vecs * rows, lds, st>>>((const char*)dy, dy_ld, nullptr, 0, npix, channels, vecs, rows, nullptr, nullptr, nullptr, nullptr, part);
+    else
+        return ODAMD_E_ARG;
+    bias_grad_finalize_kernel<<<(channels + 63) / 64, 64, 0, st>>>(part, nblk, channels, dbias);
+    return (int)hipGetLastError();
+}
+
+int odamd_maxpool2_backward(const void* x, int x_ld, const void* dy, int dy_ld, void* dx, int dx_ld, int batch, int h,
+                            int w, int c, int dtype, void* stream) {
+    if (!x || !dy || !dx || batch < 1 || h < 2 || w < 2 || c < 1) return ODAMD_E_ARG;
+    const int per = dtype == ODAMD_DTYPE_F32 ? 4 : 8;
+    if (dtype != ODAMD_DTYPE_F32 && dtype != ODAMD_DTYPE_BF16) return ODAMD_E_ARG;
+    if (c % per) return ODAMD_E_ALIGN;
+    const int vecs = c / per;
+    const size_t n = (size_t)batch * (h / 2) * (w / 2) * vecs;
+    if (dtype == ODAMD_DTYPE_F32)
+        maxpool2_bwd_kernel<ODAMD_DTYPE_F32><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>((const char*)x, x_ld, (const char*)dy, dy_ld, (char*)dx, dx_ld, batch, h, w, vecs);
+    else
+        maxpool2_bwd_kernel<ODAMD_DTYPE_BF16><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>((const char*)x, x_ld, (const char*)dy, dy_ld, (char*)dx, dx_ld, batch, h, w, vecs);
+    return (int)hipGetLastError();
+}
+
+int odamd_maxpool_s1_backward(const float* x, int x_ld, const float* dy, int dy_ld, float* dx, int dx_ld, int batch, int h,
+                              int w, int c, int ksize, void* stream) {
+    if (!x || !dy || !dx || batch < 1 || h < 1 || w < 1 || c < 1 || ksize < 1 || !(ksize & 1)) return ODAMD_E_ARG;
+    maxpool_s1_bwd_kernel<<<ew_grid((size_t)batch * h * w * c), 256, 0, (hipStream_t)stream>>>(x, x_ld, dy, dy_ld, dx, dx_ld, batch, h, w, c, ksize);
+    return (int)hipGetLastError();
+}
+
+int odamd_upsample2_backward(const void* dy, int dy_ld, void* dx, int dx_ld, int batch, int h, int w, int c, int dtype,
+                             void* stream) {
+    if (!dy || !dx || batch < 1 || h < 1 || w < 1 || c < 1) return ODAMD_E_ARG;
+    if (dtype != ODAMD_DTYPE_F32 && dtype != ODAMD_DTYPE_BF16) return ODAMD_E_ARG;
+    const int per = dtype == ODAMD_DTYPE_F32 ? 4 : 8;
+    if (c % per) return ODAMD_E_ALIGN;
+    const int vecs = c / per;
+    const size_t n = (size_t)batch * h * w * vecs;
+    if (dtype == ODAMD_DTYPE_F32)
+        upsample2_bwd_kernel<ODAMD_DTYPE_F32><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>((const char*)dy, dy_ld, (char*)dx, dx_ld, batch, h, w, vecs);
+    else
+        upsample2_bwd_kernel<ODAMD_DTYPE_BF16><<<ew_grid(n), 256, 0, (hipStream_t)stream>>>((const char*)dy, dy_ld, (char*)dx, dx_ld, batch, h, w, vecs);
+    return (int)hipGetLastError();
+}
+
+int odamd_conv_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int batch, int h, int w, int cin,
+                     int cout, int ksize, int stride, int dtype, void* stream) {
+    if (!x || !dy || !dw || batch < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return ODAMD_E_ARG;
+    if (dtype != ODAMD_DTYPE_F32) return ODAMD_E_ARG;   // bf16 activations: not built yet
+    if (!((ksize == 1 && stride == 1) || (ksize == 3 && (stride == 1 || stride == 2)))) return ODAMD_E_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || (x_ld & 3) || (dy_ld & 3)) return ODAMD_E_ALIGN;
+    WgradP p = {};
+    p.x = (const float*)x; p.dy = (const float*)dy; p.dw = dw;
+    p.B = batch; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout; p.x_ld = x_ld; p.dy_ld = dy_ld;
+    const int pad = (ksize - 1) / 2;
+    p.Ho = (h + 2 * pad - ksize) / stride + 1;
+    p.Wo = (w + 2 * pad - ksize) / stride + 1;
+    // output patch: 128 pixels (64 for stride 2), TW = 32 or the width if smaller
+    const int npix_t = stride == 2 ? 64 : 128;
+    p.TW = p.Wo < 32 ? (p.Wo >= 16 ? 16 : 8) : 32;
+    if (p.Wo == 20 || p.Wo == 40) p.TW = p.Wo == 20 ? 16 : 32;
+    p.TH = npix_t / p.TW;
+    p.tiles_x = (p.Wo + p.TW - 1) / p.TW;
+    p.tiles_y = (p.Ho + p.TH - 1) / p.TH;
+    p.IH = (p.TH - 1) * stride + ksize;
+    p.IW = (p.TW - 1) * stride + ksize;
+    p.ntiles = batch * p.tiles_x * p.tiles_y;
+    p.ncin = (cin + 31) / 32;
+    const int ncout = (cout + 31) / 32;
+    int nsplit = 2048 / (p.ncin * ncout);
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > p.ntiles) nsplit = p.ntiles;
+    p.nsplit = nsplit;
+    const size_t lds = ((size_t)p.TH * p.TW + (size_t)p.IH * p.IW) * 32 * sizeof(float);
+    dim3 grid(nsplit, p.ncin * ncout);
+    hipStream_t st = (hipStream_t)stream;
+    if (ksize == 1) conv_wgrad_f32_kernel<1, 1><<<grid, 256, lds, st>>>(p);
+    else if (stride == 1) conv_wgrad_f32_kernel<3, 1><<<grid, 256, lds, st>>>(p);
+    else conv_wgrad_f32_kernel<3, 2><<<grid, 256, lds, st>>>(p);
+    return (int)hipGetLastError();
+}
+
+size_t odamd_loss_workspace_bytes(void) { return (size_t)3 * 1024 * sizeof(double); }
+
+int odamd_detection_loss(const float* pred, float* dpred, const int* screen, const int* screen_img, const float* label,
+                         int batch, int rows, int kdim, int n_pos, float label_smooth, float* out4, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    if (!pred || !dpred || !out4 || !workspace || batch < 1 || rows < 1 || kdim < 6 || n_pos < 0) return ODAMD_E_ARG;
+    if (n_pos > 0 && (!screen || !screen_img || !label)) return ODAMD_E_ARG;
+    if (workspace_bytes < odamd_loss_workspace_bytes()) return ODAMD_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    LossP p = {pred, dpred, screen, screen_img, label, batch, rows, kdim, n_pos, label_smooth, (double*)workspace, 1024, out4};
+    int rc = (int)hipMemsetAsync(dpred, 0, (size_t)batch * rows * kdim * sizeof(float), st);
+    if (rc) return rc;
+    if (n_pos > 0) loss_mark_kernel<<<(n_pos + 255) / 256, 256, 0, st>>>(p);
+    size_t nb = ((size_t)batch * rows + 255) / 256;
+    const int nconf = (int)(nb > 1024 ? 1024 : nb);
+    loss_conf_kernel<<<nconf, 256, 0, st>>>(p);
+    int npos = 0;
+    if (n_pos > 0) {
+        npos = (n_pos + 255) / 256;
+        if (npos > 1024) npos = 1024;
+        loss_pos_kernel<<<npos, 256, 0, st>>>(p);
+    }
+    loss_finalize_kernel<<<1, 64, 0, st>>>(p, nconf, npos);
+    return (int)hipGetLastError();
+}
+
+int odamd_adam_ema_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, size_t n, double lr,
+                        double beta1, double beta2, double eps, double weight_decay, int step, double ema_decay,
+                        double grad_scale, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) return ODAMD_E_ARG;
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    adam_ema_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, ema, n, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)weight_decay, (float)ema_decay, (float)(1.0 - ema_decay), (float)grad_scale);
+    return (int)hipGetLastError();
+}
+
+int odamd_ema_update(float* ema, const float* src, size_t n, double decay, void* stream) {
+    if (!ema || !src || n < 1) return ODAMD_E_ARG;
+    ema_only_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(ema, src, n, (float)decay, (float)(1.0 - decay));
+    return (int)hipGetLastError();
+}
+
+int odamd_pack_weights(const void* table_dev, int n_entries, int dtype, void* stream) {
+    if (!table_dev || n_entries < 1) return ODAMD_E_ARG;
+    if (dtype != ODAMD_DTYPE_F32 && dtype != ODAMD_DTYPE_BF16) return ODAMD_E_ARG;
+    pack_weights_kernel<<<dim3(64, n_entries), 256, 0, (hipStream_t)stream>>>((const PackDesc*)table_dev, dtype);
+    return (int)hipGetLastError();
+}
+
+size_t odamd_pack_desc_bytes(void) { return sizeof(PackDesc); }
+
+}  // extern "C"

@@ -24,7 +24,7 @@ from ._lib import lib, check
 
 F32, BF16 = 0, 1
 _TORCH_DT = {0: torch.float32, 1: torch.bfloat16}
-CH_ALIGN = 16            # channel granule of every buffer slice (one bf16 MFMA k-step)
+CH_ALIGN = 16            # channel granule of buffer slices in bf16 plans (f32 plans use 8)
 
 _compute_dtype = None    # None: follow the parameters' dtype
 
@@ -51,8 +51,8 @@ class Act:
     are zero padding that keeps every run 16-channel aligned (pruned, irregular widths).
     """
 
-    def __init__(self, buf, c0, segments, h, w):
-        self.buf, self.c0, self.segments, self.h, self.w = buf, c0, segments, h, w
+    def __init__(self, buf, c0, segments, h, w, align=CH_ALIGN):
+        self.buf, self.c0, self.segments, self.h, self.w, self.align = buf, c0, segments, h, w, align
 
     @property
     def c(self):
@@ -61,12 +61,13 @@ class Act:
     @property
     def cphys(self):
         off, n = self.segments[-1]
-        return _round_up(off + n, CH_ALIGN)
+        return _round_up(off + n, self.align)
 
 
 class PlanBuilder:
     def __init__(self, batch, dtype, device):
         self.batch, self.dtype, self.device = batch, dtype, device
+        self.align = CH_ALIGN if dtype == BF16 else 8     # one MFMA k-step: 16 bf16 or 8 f32 channels
         self.buffers = []      # (cphys, h, w)
         self.ops = []          # dicts, resolved to launches by Plan
         self.convs = []        # ops that own packed weights
@@ -78,11 +79,11 @@ class PlanBuilder:
         segs, off = [], 0
         for n in widths:
             segs.append((off, n))
-            off += _round_up(n, CH_ALIGN)
+            off += _round_up(n, self.align)
         self.buffers.append((off, h, w))
         bid = len(self.buffers) - 1
-        whole = Act(bid, 0, segs, h, w)
-        return whole, [Act(bid, o, [(0, n)], h, w) for o, n in segs]
+        whole = Act(bid, 0, segs, h, w, self.align)
+        return whole, [Act(bid, o, [(0, n)], h, w, self.align) for o, n in segs]
 
     def single(self, c, h, w):
         return self.buffer([c], h, w)[0]
@@ -274,7 +275,7 @@ class Plan:
                 op['shift'] = torch.empty(cout, dtype=torch.float32, device=dev)
                 self.launches.append((lib.odamd_conv_first_forward,
                                       [0, op['w'].data_ptr(), op['scale'].data_ptr(), op['shift'].data_ptr(),
-                                       self._ptr(y), B, y.h, y.w, cout, self._ld(y), b.dtype], 'first', 0))
+                                       self._ptr(y), B, y.h, y.w, cout, self._ld(y), 1, b.dtype], 'first', 0))
             elif kind == 'maxpool2':
                 x, y = op['x'], op['y']
                 self.launches.append((lib.odamd_maxpool2_forward,

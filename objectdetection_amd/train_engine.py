@@ -1,0 +1,518 @@
+"""Training-step execution plan for the YOLOv7 mirror (forward in train mode, loss, backward,
+Adam + EMA) on libodamd.so.
+
+The same block-level `_emit` lowering as inference produces the op list; here every cbs becomes
+raw convolution -> train-mode BatchNorm + SiLU, the tensors backward needs are kept, and a reverse
+op list is generated from it (reference autograd of train_class.py:208-210).  Parameters live in
+one flat float32 buffer (the modules' parameters are views into it), gradients in a second flat
+buffer that is zeroed once per step and all-reduced in contiguous buckets, Adam/EMA state in
+further flat buffers updated by one fused launch (train_class.py:158-167, :477-499).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib, engine, postprocess as _post
+from ._lib import lib, check
+from .engine import F32, BF16, Act, PlanBuilder, _round_up, CH_ALIGN
+
+BN_EPS, BN_MOMENTUM = 1e-3, 0.03
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class FlatState:
+    """Flat float32 storage for parameters (+grad, Adam moments, EMA) and BN running buffers."""
+
+    def __init__(self, model):
+        dev = next(model.parameters()).device
+        params = [p for p in model.parameters()]
+        self.offsets, n = {}, 0
+        for p in params:
+            self.offsets[id(p)] = n
+            n += _round_up(p.numel(), 4)            # keep every tensor 16-byte aligned
+        self.n = n
+        self.param = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p in params:
+                o = self.offsets[id(p)]
+                view = self.param[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data.float())
+                p.data = view
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        bufs = [b for b in model.buffers() if b.dtype.is_floating_point]
+        self.buf_offsets, nb = {}, 0
+        for b in bufs:
+            self.buf_offsets[id(b)] = nb
+            nb += _round_up(b.numel(), 4)
+        self.nb = nb
+        self.buffers = torch.zeros(max(nb, 4), dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for name, b in list(model.named_buffers()):
+                if not b.dtype.is_floating_point:
+                    continue
+                o = self.buf_offsets[id(b)]
+                view = self.buffers[o:o + b.numel()].view(b.shape)
+                view.copy_(b)
+                mod = model
+                *path, leaf = name.split('.')
+                for part in path:
+                    mod = getattr(mod, part)
+                mod._buffers[leaf] = view
+        self.ema_param = None
+        self.ema_buffers = None
+        self.step = 0
+        self.ema_updates = 0
+
+    def enable_ema(self):
+        self.ema_param = self.param.clone()
+        self.ema_buffers = self.buffers.clone()
+
+    def grad_ptr(self, p):
+        return self.grad.data_ptr() + 4 * self.offsets[id(p)]
+
+
+class GradReducer:
+    """Bucketed data-parallel gradient all-reduce over torch.distributed (RCCL on GPUs, gloo in the
+    CPU tests).  The flat gradient buffer is cut into contiguous buckets; bucket i is started as
+    soon as the backward pass reports that everything inside it is final (`ready`), so the
+    collectives run behind the remaining backward kernels (DDP of train_class.py:37-40)."""
+
+    def __init__(self, flat_grad, n_buckets=3, group=None):
+        import torch.distributed as dist
+        self.dist, self.group, self.flat = dist, group, flat_grad
+        n = flat_grad.numel()
+        per = -(-n // n_buckets)
+        self.bounds = [(i * per, min(n, (i + 1) * per)) for i in range(n_buckets) if i * per < n]
+        self.handles = []
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def bucket_of(self, offset):
+        for i, (a, b) in enumerate(self.bounds):
+            if a <= offset < b:
+                return i
+        return len(self.bounds) - 1
+
+    def ready(self, i):
+        if self.world > 1:
+            a, b = self.bounds[i]
+            self.handles.append(self.dist.all_reduce(self.flat[a:b], op=self.dist.ReduceOp.SUM, group=self.group,
+                                                     async_op=True))
+
+    def finish(self):
+        """Wait for all buckets; returns the factor that turns the sum into the mean."""
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        return 1.0 / self.world
+
+
+class TrainPlan:
+    """Forward (train mode) + backward launch lists for one (batch, size, dtype)."""
+
+    def __init__(self, model, state, batch, size, dtype=F32, block_input=None):
+        """`model`: a yolov7 mirror (whole network incl. decode), or any block when `block_input`
+        = (channels, height, width) is given (NCHW float32 in, NCHW float32 out; used by tests)."""
+        if dtype != F32:
+            raise NotImplementedError('the training step computes in float32 in this version')
+        self.model, self.state, self.batch, self.size, self.dtype = model, state, batch, size, dtype
+        dev = state.param.device
+        self.dev = dev
+        pb = PlanBuilder(batch, dtype, dev)
+        self.block = block_input is not None
+        if self.block:
+            c, h, w = block_input
+            out = model._emit(pb, pb.from_nchw(c, h, w))
+            pb.to_nchw(out)
+            self.head_ops = []
+            self.out_nchw = torch.empty((batch, out.c, out.h, out.w), dtype=torch.float32, device=dev)
+            self.gout_nchw = torch.empty_like(self.out_nchw)
+            self.dx_nchw = torch.empty((batch, c, h, w), dtype=torch.float32, device=dev)
+        else:
+            self.head_ops = model._emit(pb, (size, size))
+        self.pb = pb
+        self.es = 4
+        self._lower()
+
+    # ---- helpers ---------------------------------------------------------------------------
+    def _aptr(self, act):
+        return self.bufs[act.buf].data_ptr() + act.c0 * self.es
+
+    def _gptr(self, act):
+        return self.gbufs[act.buf].data_ptr() + act.c0 * self.es
+
+    def _ld(self, act):
+        return self.bufs[act.buf].shape[3]
+
+    def _lower(self):
+        pb, dev, B = self.pb, self.dev, self.batch
+        st = self.state
+        # conv(pool=True) -> explicit max pool + conv (its backward needs the pooled tensor)
+        ops = []
+        for op in pb.ops:
+            if op['kind'] == 'conv' and op['pool']:
+                pooled = pb.single(op['x'].c, op['x'].h // 2, op['x'].w // 2)
+                ops.append(dict(kind='maxpool2', x=op['x'], y=pooled))
+                op = dict(op, x=pooled, pool=False)
+            ops.append(op)
+        self.ops = ops
+        # activation buffers and their gradients (one pool, zeroed once per step)
+        self.bufs = [torch.zeros((B, h, w, c), dtype=torch.float32, device=dev) for c, h, w in pb.buffers]
+        total = sum(t.numel() for t in self.bufs)
+        self.grad_pool = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.gbufs, o = [], 0
+        for t in self.bufs:
+            self.gbufs.append(self.grad_pool[o:o + t.numel()].view(t.shape))
+            o += t.numel()
+        self.image8 = None if self.block else torch.zeros((B, self.size, self.size, 8), dtype=torch.float32, device=dev)
+        maxc = 16
+        self.fwd, self.bwd = [], []
+        self.keep = []
+        pack = []
+        self.bucket_marks = {}
+        for op in ops:
+            kind = op['kind']
+            if kind in ('conv', 'first'):
+                m = op['mod']
+                cout = m.conv.out_channels
+                cphys = _round_up(cout, self.pb.align)
+                y_act = op['y']
+                ho, wo = y_act.h, y_act.w
+                raw = torch.zeros((B, ho, wo, cphys), dtype=torch.float32, device=dev)
+                stats = torch.zeros((4, cout), dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
+                op['raw'], op['stats'] = raw, stats
+                maxc = max(maxc, cphys)
+                npix = B * ho * wo
+                k = m.conv.kernel_size[0]
+                if kind == 'first':
+                    wf = torch.empty(cout * 27, dtype=torch.float32, device=dev)
+                    pack.append(self._pack_desc(m.conv.weight, wf, None, None, cout))
+                    op['wf'] = wf
+                    self.fwd.append((lib.odamd_conv_first_forward,
+                                     [None, wf.data_ptr(), None, None, raw.data_ptr(), B, ho, wo, cout, cphys, 0,
+                                      self.dtype], 'first', 0))
+                else:
+                    x = op['x']
+                    assert x.cphys == x.c, 'training needs gap-free channel slices (widths that are multiples of 16)'
+                    wf = torch.empty(cout * k * k * x.cphys, dtype=torch.float32, device=dev)
+                    wb = torch.zeros(x.cphys * k * k * cphys, dtype=torch.float32, device=dev)
+                    pack.append(self._pack_desc(m.conv.weight, wf, wb, x, cout))
+                    op['wf'], op['wb'] = wf, wb
+                    d = self._conv_desc(self._aptr(x), wf, None, raw.data_ptr(), x.h, x.w, x.cphys, cout, self._ld(x),
+                                        cphys, k, op['s'])
+                    self.fwd.append((lib.odamd_conv_forward, [C.byref(d)], 'conv', None))
+                self.fwd.append(('bn_fwd', (op, npix, cout, cphys), 'bn', None))
+            elif kind == 'head':
+                m, x = op['mod'], op['x']
+                cout = m.output.out_channels
+                cphys = _round_up(cout, self.pb.align)
+                wf = torch.empty(cout * x.cphys, dtype=torch.float32, device=dev)
+                wb = torch.zeros(x.cphys * cphys, dtype=torch.float32, device=dev)
+                pack.append(self._pack_desc(m.output.weight, wf, wb, x, cout))
+                out = torch.empty((B, cout, x.h, x.w), dtype=torch.float32, device=dev)
+                dyb = torch.zeros((B, x.h, x.w, cphys), dtype=torch.float32, device=dev)
+                op.update(wf=wf, wb=wb, out=out, dy=dyb)
+                maxc = max(maxc, cphys)
+                d = self._conv_desc(self._aptr(x), wf, m.output.bias, out.data_ptr(), x.h, x.w, x.cphys, cout,
+                                    self._ld(x), 0, 1, 1, nchw=1)
+                self.fwd.append((lib.odamd_conv_forward, [C.byref(d)], 'head', None))
+            elif kind == 'maxpool2':
+                x, y = op['x'], op['y']
+                self.fwd.append((lib.odamd_maxpool2_forward,
+                                 [self._aptr(x), self._aptr(y), B, x.h, x.w, x.cphys, self._ld(x), self._ld(y),
+                                  self.dtype], 'maxpool2', None))
+            elif kind == 'spp':
+                x, ys = op['x'], op['ys']
+                self.fwd.append((lib.odamd_spp_pool3_forward,
+                                 [self._aptr(x), self._aptr(ys[0]), self._aptr(ys[1]), self._aptr(ys[2]), B, x.h, x.w,
+                                  x.cphys, self._ld(x), self._ld(ys[0]), self.dtype], 'spp', None))
+            elif kind == 'upsample2':
+                x, y = op['x'], op['y']
+                self.fwd.append((lib.odamd_upsample2_forward,
+                                 [self._aptr(x), self._aptr(y), B, x.h, x.w, x.cphys, self._ld(x), self._ld(y),
+                                  self.dtype], 'upsample2', None))
+            elif kind == 'from_nchw':
+                y = op['y']
+                self.fwd.append((lib.odamd_nchw_to_nhwc,
+                                 [None, self._aptr(y), B, y.c, y.h, y.w, y.c, self._ld(y), self.dtype], 'from_nchw', 0))
+            elif kind == 'to_nchw':
+                x, dst = op['x'], 0
+                for off, n in x.segments:
+                    self.fwd.append((lib.odamd_nhwc_to_nchw,
+                                     [self._aptr(x) + off * 4, self.out_nchw.data_ptr() + dst * x.h * x.w * 4, B, n, x.h,
+                                      x.w, self._ld(x), x.c, self.dtype], 'to_nchw', None))
+                    dst += n
+            else:
+                raise AssertionError(kind)
+        # packing table
+        arr = (_lib.PackDesc * len(pack))(*pack)
+        self.pack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.n_pack = len(pack)
+        self.ws = torch.empty(int(lib.odamd_bn_workspace_bytes(maxc)) + 8 * maxc, dtype=torch.uint8, device=dev)
+        self.loss_ws = torch.empty(int(lib.odamd_loss_workspace_bytes()), dtype=torch.uint8, device=dev)
+        self.loss_out = torch.zeros(4, dtype=torch.float32, device=dev)
+        if not self.block:
+            k = 5 + self.model.output_class
+            rows = sum(o['out'].shape[1] // k * o['out'].shape[2] * o['out'].shape[3] for o in self.head_ops)
+            self.pred = torch.empty((B, rows, k), dtype=torch.float32, device=dev)
+            self.dpred = torch.empty_like(self.pred)
+            self.dheads = [torch.empty_like(o['out']) for o in self.head_ops]
+        self._lower_backward()
+
+    def _pack_desc(self, w, fwd, bwd, x_act, cout):
+        d = _lib.PackDesc()
+        d.w = w.data_ptr()
+        d.fwd = fwd.data_ptr()
+        d.bwd = bwd.data_ptr() if bwd is not None else None
+        d.cout, d.cin, d.k = w.shape[0], w.shape[1], w.shape[2]
+        d.cin_phys = x_act.cphys if x_act is not None else w.shape[1]
+        d.cout_phys = _round_up(cout, self.pb.align)
+        segs = x_act.segments if x_act is not None else [(0, w.shape[1])]
+        d.n_seg = len(segs)
+        for i, (off, n) in enumerate(segs):
+            d.seg_off[i], d.seg_len[i] = off, n
+        return d
+
+    def _conv_desc(self, x_ptr, w, shift, y_ptr, h, w_in, cin, cout, x_ld, y_ld, k, s, nchw=0, upz=0, accum=0):
+        d = _lib.ConvDesc()
+        d.x, d.w, d.scale = x_ptr, w.data_ptr(), None
+        d.shift = shift.data_ptr() if shift is not None else None
+        d.y = y_ptr
+        d.batch, d.h, d.w_in, d.cin, d.cout = self.batch, h, w_in, cin, cout
+        d.x_ld, d.y_ld, d.ksize, d.stride, d.act = x_ld, y_ld, k, s, 0
+        d.dtype, d.in_pool2, d.out_nchw_f32, d.in_upzero2, d.accumulate = self.dtype, 0, nchw, upz, accum
+        self.keep.append(d)
+        return d
+
+    def _lower_backward(self):
+        B, st = self.batch, self.state
+        bwd = []
+        for op in reversed(self.ops):
+            kind = op['kind']
+            if kind in ('conv', 'first'):
+                m = op['mod']
+                cout = m.conv.out_channels
+                raw = op['raw']
+                cphys = raw.shape[3]
+                k = m.conv.kernel_size[0]
+                npix = B * raw.shape[1] * raw.shape[2]
+                bwd.append(('bn_bwd', (op, npix, cout, cphys), 'bn_bwd', None))
+                if kind == 'first':
+                    bwd.append((lib.odamd_conv_wgrad,
+                                [self.image8.data_ptr(), 8, raw.data_ptr(), cphys, st.grad_ptr(m.conv.weight), B,
+                                 self.size, self.size, 3, cout, 3, 1, self.dtype], 'wgrad', None))
+                else:
+                    x = op['x']
+                    bwd.append((lib.odamd_conv_wgrad,
+                                [self._aptr(x), self._ld(x), raw.data_ptr(), cphys, st.grad_ptr(m.conv.weight), B, x.h,
+                                 x.w, x.c, cout, k, op['s'], self.dtype], 'wgrad', None))
+                    d = self._conv_desc(raw.data_ptr(), op['wb'], None, self._gptr(x), raw.shape[1], raw.shape[2], cphys,
+                                        x.cphys, cphys, self._ld(x), k, 1, upz=int(op['s'] == 2), accum=1)
+                    bwd.append((lib.odamd_conv_forward, [C.byref(d)], 'dgrad', None))
+                bwd.append(('mark', (m.conv.weight, m.bn.weight, m.bn.bias), 'mark', None))
+            elif kind == 'head':
+                m, x = op['mod'], op['x']
+                cout = m.output.out_channels
+                dyb = op['dy']
+                cphys = dyb.shape[3]
+                i = self.head_ops.index(op)
+                npix = B * x.h * x.w
+                bwd.append((lib.odamd_nchw_to_nhwc,
+                            [self.dheads[i].data_ptr(), dyb.data_ptr(), B, cout, x.h, x.w, cout, cphys, self.dtype],
+                            'to_nhwc', None))
+                bwd.append((lib.odamd_bias_grad,
+                            [dyb.data_ptr(), cphys, npix, cphys, None, self.dtype, self.ws.data_ptr(), self.ws.numel()],
+                            'bias_grad', ('bias', m.output.bias, cout, cphys)))
+                bwd.append((lib.odamd_conv_wgrad,
+                            [self._aptr(x), self._ld(x), dyb.data_ptr(), cphys, st.grad_ptr(m.output.weight), B, x.h,
+                             x.w, x.c, cout, 1, 1, self.dtype], 'wgrad', None))
+                d = self._conv_desc(dyb.data_ptr(), op['wb'], None, self._gptr(x), x.h, x.w, cphys, x.cphys, cphys,
+                                    self._ld(x), 1, 1, accum=1)
+                bwd.append((lib.odamd_conv_forward, [C.byref(d)], 'dgrad', None))
+                bwd.append(('mark', (m.output.weight, m.output.bias), 'mark', None))
+            elif kind == 'maxpool2':
+                x, y = op['x'], op['y']
+                bwd.append((lib.odamd_maxpool2_backward,
+                            [self._aptr(x), self._ld(x), self._gptr(y), self._ld(y), self._gptr(x), self._ld(x), B, x.h,
+                             x.w, x.cphys, self.dtype], 'maxpool2_bwd', None))
+            elif kind == 'spp':
+                x, ys = op['x'], op['ys']
+                for y, kk in zip(ys, (5, 9, 13)):
+                    bwd.append((lib.odamd_maxpool_s1_backward,
+                                [self._aptr(x), self._ld(x), self._gptr(y), self._ld(y), self._gptr(x), self._ld(x), B,
+                                 x.h, x.w, x.cphys, kk], 'spp_bwd', None))
+            elif kind == 'from_nchw':
+                y = op['y']
+                bwd.append((lib.odamd_nhwc_to_nchw,
+                            [self._gptr(y), self.dx_nchw.data_ptr(), B, y.c, y.h, y.w, self._ld(y), y.c, self.dtype],
+                            'dx_to_nchw', None))
+            elif kind == 'to_nchw':
+                x, dst = op['x'], 0
+                for off, n in x.segments:
+                    bwd.append((lib.odamd_nchw_to_nhwc,
+                                [self.gout_nchw.data_ptr() + dst * x.h * x.w * 4, self._gptr(x) + off * 4, B, n, x.h, x.w,
+                                 x.c, self._ld(x), self.dtype], 'gout_to_nhwc', None))
+                    dst += n
+            elif kind == 'upsample2':
+                x, y = op['x'], op['y']
+                bwd.append((lib.odamd_upsample2_backward,
+                            [self._gptr(y), self._ld(y), self._gptr(x), self._ld(x), B, x.h, x.w, x.cphys, self.dtype],
+                            'upsample2_bwd', None))
+        self.bwd = bwd
+        # scratch for the head bias gradient (padded channel count), added to the real slot afterwards
+        self.bias_tmp = {}
+
+    # ---- execution -------------------------------------------------------------------------
+    def _bn_fwd(self, op, npix, cout, cphys, stream):
+        m, raw, stats = op['mod'], op['raw'], op['stats']
+        y = op['y']
+        check(lib.odamd_bn_train_forward(raw.data_ptr(), cphys, self._aptr(y), self._ld(y), npix, cout,
+                                         m.bn.weight.data_ptr(), m.bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM,
+                                         m.bn.running_mean.data_ptr(), m.bn.running_var.data_ptr(),
+                                         stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+                                         stats[3].data_ptr(), self.dtype, self.ws.data_ptr(), self.ws.numel(), stream),
+              'bn_train_forward')
+
+    def _bn_bwd(self, op, npix, cout, cphys, stream):
+        m, raw, stats = op['mod'], op['raw'], op['stats']
+        y = op['y']
+        st = self.state
+        check(lib.odamd_bn_silu_backward(raw.data_ptr(), cphys, self._gptr(y), self._ld(y), npix, cout,
+                                         stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
+                                         stats[1].data_ptr(), st.grad_ptr(m.bn.weight), st.grad_ptr(m.bn.bias),
+                                         self.dtype, self.ws.data_ptr(), self.ws.numel(), stream), 'bn_silu_backward')
+
+    def forward(self, image):
+        """Train-mode forward; returns the decoded (B,R,K) prediction (decode leaves channels 4: raw)."""
+        stream = _stream()
+        check(lib.odamd_pack_weights(self.pack_table.data_ptr(), self.n_pack, self.dtype, stream), 'pack_weights')
+        img = image.data_ptr()
+        for fn, args, name, slot in self.fwd:
+            if fn == 'bn_fwd':
+                self._bn_fwd(*args, stream)
+                continue
+            if slot is not None:
+                args[slot] = img
+            check(fn(*args, stream), name)
+        for m in self.model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.num_batches_tracked += 1
+        if self.block:
+            return self.out_nchw
+        k = 5 + self.model.output_class
+        heads = [o['out'].view(self.batch, o['out'].shape[1] // k, o['out'].shape[2], o['out'].shape[3], k)
+                 for o in self.head_ops]
+        self.heads = heads
+        dec = self.model.decode
+        d = _post.decode_desc(heads, dec.input_size, dec.anchor_rel, False)
+        self.decode_desc = d
+        check(lib.odamd_decode(C.byref(d), self.pred.data_ptr(), stream), 'decode')
+        return self.pred
+
+    def loss(self, screen_list, label_expend, label_smooth):
+        """loss_class.__call__ on the last forward's prediction; fills self.dpred; returns a (4,) tensor."""
+        dev = self.dev
+        idx, img = [], []
+        for b, s in enumerate(screen_list):
+            if len(s):
+                idx.append(s.to(torch.int32))
+                img.append(torch.full((len(s),), b, dtype=torch.int32))
+        n_pos = sum(len(i) for i in idx)
+        if n_pos:
+            screen = torch.cat(idx).to(dev)
+            simg = torch.cat(img).to(dev)
+            label = label_expend.to(dev, torch.float32).contiguous()
+            sp, ip, lp = screen.data_ptr(), simg.data_ptr(), label.data_ptr()
+            self._keep_loss = (screen, simg, label)
+        else:
+            sp = ip = lp = None
+        b, r, k = self.pred.shape
+        check(lib.odamd_detection_loss(self.pred.data_ptr(), self.dpred.data_ptr(), sp, ip, lp, b, r, k, n_pos,
+                                       float(label_smooth), self.loss_out.data_ptr(), self.loss_ws.data_ptr(),
+                                       self.loss_ws.numel(), _stream()), 'detection_loss')
+        return self.loss_out
+
+    def backward(self, image, reducer=None):
+        """Backward of the last forward from self.dpred; gradients are ADDED to state.grad."""
+        stream = _stream()
+        self.grad_pool.zero_()
+        if not self.block:
+            check(lib.odamd_nchw_to_nhwc(image.data_ptr(), self.image8.data_ptr(), self.batch, 3, self.size, self.size, 3,
+                                         8, self.dtype, stream), 'image_to_nhwc')
+            arr = (C.c_void_p * 3)(*[g.data_ptr() for g in self.dheads])
+            check(lib.odamd_decode_backward(C.byref(self.decode_desc), self.dpred.data_ptr(), C.byref(arr), stream),
+                  'decode_backward')
+        pending = None
+        if reducer is not None:
+            pending = self._bucket_plan(reducer)
+        for i, (fn, args, name, extra) in enumerate(self.bwd):
+            if fn == 'bn_bwd':
+                self._bn_bwd(*args, stream)
+            elif fn == 'mark':
+                if pending is not None:
+                    for bucket in pending.pop(i, ()):
+                        reducer.ready(bucket)
+            elif name == 'bias_grad':
+                _, bias, cout, cphys = extra
+                tmp = self.bias_tmp.get(id(bias))
+                if tmp is None:
+                    tmp = self.bias_tmp[id(bias)] = torch.zeros(cphys, dtype=torch.float32, device=self.dev)
+                tmp.zero_()
+                args[4] = tmp.data_ptr()
+                check(fn(*args, stream), name)
+                bias.grad.add_(tmp[:cout])
+            else:
+                check(fn(*args, stream), name)
+
+    def _bucket_plan(self, reducer):
+        """launch index of the 'mark' after which a bucket's last gradient has been written."""
+        st = self.state
+        last = {}
+        for i, (fn, args, name, _) in enumerate(self.bwd):
+            if fn == 'mark':
+                for p in args:
+                    last[reducer.bucket_of(st.offsets[id(p)])] = i
+        plan = {}
+        for bucket, i in last.items():
+            plan.setdefault(i, []).append(bucket)
+        for b in range(len(reducer.bounds)):
+            if b not in last:
+                plan.setdefault(max(last.values()), []).append(b)
+        return plan
+
+
+def lr_schedule(step_now, lr_start, lr_end, step_all, warmup_step):
+    """lr_adjust.__call__ (train_class.py:511-521) for the already incremented step counter."""
+    lr = lr_end + (lr_start - lr_end) * math.cos(math.pi / 2 * step_now / step_all)
+    if step_now <= warmup_step:
+        lr = lr * (0.1 + 0.9 * step_now / warmup_step)
+    return max(lr, 0.000001)
+
+
+def ema_decay(update_total, decay=0.9999, tau=2000):
+    """model_ema.decay (train_class.py:481)."""
+    return decay * (1 - math.exp(-update_total / tau))
+
+
+def optimizer_step(state, lr, weight_decay=0.0005, betas=(0.937, 0.999), eps=1e-8, grad_scale=1.0, ema=True):
+    """Adam with coupled L2 over the flat buffers, fused with the EMA of the parameters; the EMA
+    of the BN running buffers follows in a second launch (train_class.py:211-213)."""
+    state.step += 1
+    d = 0.0
+    ema_ptr = None
+    if ema and state.ema_param is not None:
+        state.ema_updates += 1
+        d = ema_decay(state.ema_updates)
+        ema_ptr = state.ema_param.data_ptr()
+    check(lib.odamd_adam_ema_step(state.param.data_ptr(), state.grad.data_ptr(), state.exp_avg.data_ptr(),
+                                  state.exp_avg_sq.data_ptr(), ema_ptr, state.n, lr, betas[0], betas[1], eps,
+                                  weight_decay, state.step, d, grad_scale, _stream()), 'adam_ema_step')
+    if ema_ptr is not None and state.nb:
+        check(lib.odamd_ema_update(state.ema_buffers.data_ptr(), state.buffers.data_ptr(), state.nb, d, _stream()),
+              'ema_update')

@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, REF)
 for name in ('cv2', 'wandb', 'torchvision'):
     sys.modules.setdefault(name, types.ModuleType(name))
+_ARGV = list(sys.argv)
 sys.argv = ['make_golden']
 
 from oracle import patterns  # noqa: E402
@@ -129,6 +130,44 @@ def gen_net():
             if n in ('cbs0.bn.running_mean', 'cbs0.bn.running_var', 'elan_h25.cbs7.bn.running_var'):
                 out[f'{tag}.buf.{n}'] = b.numpy()
     save('net.npz', **out)
+
+
+def gen_net128():
+    """Training step at 128x128, batch 4 (deepest maps 4x4 -> 64 values per BN channel): a better
+    conditioned whole-network check than the 64x64 case; only small tensors are stored."""
+    out = {}
+    tag, size, ncls, batch = 's128', 128, 5, 4
+    args = patterns.default_args(input_size=size, output_class=ncls)
+    net = ref_yolov7(args)
+    patterns.fill_state_dict(net)
+    x = patterns.image_batch(batch, size)
+    net.train()
+    pred = net(x.clone())
+    out[f'{tag}.train_sample'] = pred.detach().numpy()[:, ::7]
+    r = pred.shape[1]
+    screen = [torch.tensor(sorted({(11 * i + 5 * b) % r for i in range(12)}), dtype=torch.int64) for b in range(batch)]
+    npos = sum(len(s) for s in screen)
+    lab = patterns.wave('label128', (npos, 5 + ncls), 0.4, 0.5)
+    lab[:, 0:2] = lab[:, 0:2] * size
+    lab[:, 2:4] = lab[:, 2:4] * size * 0.5 + 4
+    largs = argparse.Namespace(device='cpu', input_size=size, output_size=args.output_size, label_smooth=0.01,
+                               output_class=ncls)
+    loss, fl, cl, kl = ref_train.loss_class(largs)(pred, screen, lab)
+    loss.backward()
+    out[f'{tag}.loss'] = np.array([loss.item(), fl.item(), cl.item(), kl.item()], f32)
+    out[f'{tag}.label'] = lab.numpy()
+    for b, s in enumerate(screen):
+        out[f'{tag}.screen{b}'] = s.numpy()
+    for n, p in net.named_parameters():
+        g = p.grad
+        if n in ('cbs0.conv.weight', 'cbs3.bn.weight', 'elan_h19.cbs7.bn.bias', 'head0.output.weight',
+                 'head2.output.bias', 'mp20.cbs3.conv.weight', 'elan4.cbs1.conv.weight'):
+            out[f'{tag}.grad.{n}'] = g.numpy()
+        out[f'{tag}.gnorm.{n}'] = np.array([g.double().norm().item(), g.double().sum().item()])
+    for n, b in net.named_buffers():
+        if n in ('cbs0.bn.running_mean', 'cbs0.bn.running_var', 'elan_h25.cbs7.bn.running_var'):
+            out[f'{tag}.buf.{n}'] = b.numpy()
+    save('net128.npz', **out)
 
 
 # --------------------------------------------------------------------------- decode
@@ -279,7 +318,11 @@ def gen_training():
 
 
 if __name__ == '__main__':
+    if len(_ARGV) > 1 and _ARGV[1] == 'net128':
+        gen_net128()
+        sys.exit(0)
     gen_blocks()
+    gen_net128()
     gen_net()
     gen_decode()
     gen_nms()
