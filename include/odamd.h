@@ -181,8 +181,8 @@ size_t odamd_bn_workspace_bytes(int channels);
 
 /* cbs.bn + cbs.silu in train mode (model/layer.py:14-15): batch statistics of the raw convolution
  * output y over npix = B*H*W pixels, running buffers updated (momentum, unbiased variance),
- * out = silu(y*scale + shift) written with pixel stride out_ld.  mean/invstd/scale/shift (channels
- * floats each) are kept for the backward pass. */
+ * out = silu((y - mean)*scale + shift) written with pixel stride out_ld, scale = gamma*invstd, shift =
+ * beta.  mean/invstd/scale/shift (channels floats each) are kept for the backward pass. */
 int odamd_bn_train_forward(const void* y, int y_ld, void* out, int out_ld, size_t npix, int channels,
                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                            float* running_var, float* mean, float* invstd, float* scale, float* shift, int dtype,

@@ -217,6 +217,18 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
         ODAMD_COMMIT()
         __syncthreads();
         if (c0 + CKB < cbytes) ODAMD_FETCH(c0 + CKB)  // in flight while the matrix cores work
+        // float32: every chunk accumulates into a fresh tile that is then added to the running sum,
+        // so the rounding-error chain is (taps * channels per chunk) + (number of chunks) long
+        // instead of the whole k*k*cin reduction (matters once k*k*cin reaches the thousands).
+        f32x16_t part[DT == ODAMD_DTYPE_F32 ? PGW : 1][DT == ODAMD_DTYPE_F32 ? CGW : 1];
+        if constexpr (DT == ODAMD_DTYPE_F32) {
+#pragma unroll
+            for (int i = 0; i < PGW; ++i)
+#pragma unroll
+                for (int j = 0; j < CGW; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) part[i][j][e] = 0.0f;
+        }
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int tap_off = ((tap / KS) * p.IW + (tap % KS)) * PS;
@@ -230,8 +242,19 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
 #pragma unroll
                 for (int i = 0; i < PGW; ++i)
 #pragma unroll
-                    for (int j = 0; j < CGW; ++j) mma_step<DT>(acc[i][j], a[j], bb[i]);
+                    for (int j = 0; j < CGW; ++j) {
+                        if constexpr (DT == ODAMD_DTYPE_F32) mma_step<DT>(part[i][j], a[j], bb[i]);
+                        else mma_step<DT>(acc[i][j], a[j], bb[i]);
+                    }
             }
+        }
+        if constexpr (DT == ODAMD_DTYPE_F32) {
+#pragma unroll
+            for (int i = 0; i < PGW; ++i)
+#pragma unroll
+                for (int j = 0; j < CGW; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] += part[i][j][e];
         }
         __syncthreads();
     }

@@ -67,25 +67,33 @@ channel_reduce_kernel(const char* __restrict__ y, int y_ld, const char* __restri
     const int v = threadIdx.x % vecs, r = threadIdx.x / vecs;
     const size_t per = (npix + gridDim.x - 1) / gridDim.x;
     const size_t p0 = (size_t)blockIdx.x * per, p1 = min(npix, p0 + per);
-    float s0[N], s1[N], sc[N], sh[N], mu[N], is[N];
+    float s0[N], s1[N], sc[N], sh[N], mu[N], is[N], piv[N];
 #pragma unroll
     for (int e = 0; e < N; ++e) {
         s0[e] = 0.f; s1[e] = 0.f;
         const int c = v * N + e;
         if (MODE == 1) { sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c]; }
     }
+    // MODE 0 sums (y - pivot) and (y - pivot)^2 with pivot = the channel's value at pixel 0: the
+    // variance then comes from numbers of the size of the spread, not of the mean (no cancellation)
+    if (MODE == 0) {
+        Vec<DT>::load(y + v * 16, piv);
+        if (blockIdx.x == 0 && r == 0)
+#pragma unroll
+            for (int e = 0; e < N; ++e) part[(size_t)gridDim.x * 2 * C + v * N + e] = (double)piv[e];
+    }
     for (size_t p = p0 + r; p < p1; p += rows) {
         float a[N];
         Vec<DT>::load(y + (p * y_ld) * ES + v * 16, a);
         if (MODE == 0) {
 #pragma unroll
-            for (int e = 0; e < N; ++e) { s0[e] += a[e]; s1[e] += a[e] * a[e]; }
+            for (int e = 0; e < N; ++e) { const float d = a[e] - piv[e]; s0[e] += d; s1[e] += d * d; }
         } else if (MODE == 1) {
             float g[N];
             Vec<DT>::load(dact + (p * d_ld) * ES + v * 16, g);
 #pragma unroll
             for (int e = 0; e < N; ++e) {
-                const float dz = g[e] * silu_grad(a[e] * sc[e] + sh[e]);
+                const float dz = g[e] * silu_grad((a[e] - mu[e]) * sc[e] + sh[e]);
                 s0[e] += dz;
                 s1[e] += dz * ((a[e] - mu[e]) * is[e]);
             }
@@ -121,15 +129,16 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ part, int nb
     if (c >= C) return;
     double s = 0.0, q = 0.0;
     for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
-    const double m = s / npix;
-    double var = q / npix - m * m;
+    const double md = s / npix;                    // mean of (y - pivot)
+    double var = q / npix - md * md;
     if (var < 0.0) var = 0.0;
+    const double m = part[(size_t)nblk * 2 * C + c] + md;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     mean[c] = (float)m;
     invstd[c] = is;
     const float sc = gamma[c] * is;
     scale[c] = sc;
-    shift[c] = beta[c] - (float)m * sc;
+    shift[c] = beta[c];   // z = (y - mean)*scale + beta: subtracting the mean first keeps the cancellation exact
     if (running_mean) {
         const double unb = npix > 1.0 ? var * npix / (npix - 1.0) : var;
         running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
@@ -159,11 +168,11 @@ __global__ void bias_grad_finalize_kernel(const double* __restrict__ part, int n
     dbias[c] += (float)s;
 }
 
-// act = silu(y*scale + shift), written at a channel offset of a wider buffer.
+// act = silu((y - mean)*scale + beta), written at a channel offset of a wider buffer (shift holds beta).
 template <int DT>
 __global__ void __launch_bounds__(256)
 bn_apply_silu_kernel(const char* __restrict__ y, int y_ld, char* __restrict__ out, int o_ld, size_t npix, int vecs,
-                     const float* __restrict__ scale, const float* __restrict__ shift) {
+                     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean) {
     constexpr int N = Vec<DT>::N, ES = Vec<DT>::ES;
     const size_t n = npix * vecs;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -172,7 +181,7 @@ bn_apply_silu_kernel(const char* __restrict__ y, int y_ld, char* __restrict__ ou
         float a[N];
         Vec<DT>::load(y + (p * y_ld) * ES + v * 16, a);
 #pragma unroll
-        for (int e = 0; e < N; ++e) a[e] = silu_f(a[e] * scale[v * N + e] + shift[v * N + e]);
+        for (int e = 0; e < N; ++e) a[e] = silu_f((a[e] - mean[v * N + e]) * scale[v * N + e] + shift[v * N + e]);
         Vec<DT>::store(out + (p * o_ld) * ES + v * 16, a);
     }
 }
@@ -195,7 +204,7 @@ bn_bwd_apply_kernel(char* __restrict__ y, int y_ld, const char* __restrict__ dac
 #pragma unroll
         for (int e = 0; e < N; ++e) {
             const int c = v * N + e;
-            const float dz = g[e] * silu_grad(a[e] * scale[c] + shift[c]);
+            const float dz = g[e] * silu_grad((a[e] - mean[c]) * scale[c] + shift[c]);
             const float xh = (a[e] - mean[c]) * invstd[c];
             a[e] = scale[c] * (dz - mean_dz[c] - xh * mean_dzx[c]);   // scale = gamma * invstd
         }
@@ -634,7 +643,7 @@ int ew_grid(size_t n) {
 
 extern "C" {
 
-size_t odamd_bn_workspace_bytes(int channels) { return (size_t)RED_MAX_BLOCKS * 2 * channels * sizeof(double); }
+size_t odamd_bn_workspace_bytes(int channels) { return ((size_t)RED_MAX_BLOCKS * 2 + 1) * channels * sizeof(double); }
 
 int odamd_bn_train_forward(const void* y, int y_ld, void* out, int out_ld, size_t npix, int channels, const float* gamma,
                            const float* beta, float eps, float momentum, float* running_mean, float* running_var,
@@ -657,9 +666,9 @@ int odamd_bn_train_forward(const void* y, int y_ld, void* out, int out_ld, size_
         channel_reduce_kernel<ODAMD_DTYPE_BF16, 0><<<nblk, vecs * rows, lds, st>>>((const char*)y, y_ld, nullptr, 0, npix, channels, vecs, rows, nullptr, nullptr, nullptr, nullptr, part);
     bn_stats_finalize_kernel<<<(channels + 63) / 64, 64, 0, st>>>(part, nblk, channels, (double)npix, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
     if (dtype == ODAMD_DTYPE_F32)
-        bn_apply_silu_kernel<ODAMD_DTYPE_F32><<<ew_grid(npix * vecs), 256, 0, st>>>((const char*)y, y_ld, (char*)out, out_ld, npix, vecs, scale, shift);
+        bn_apply_silu_kernel<ODAMD_DTYPE_F32><<<ew_grid(npix * vecs), 256, 0, st>>>((const char*)y, y_ld, (char*)out, out_ld, npix, vecs, scale, shift, mean);
     else
-        bn_apply_silu_kernel<ODAMD_DTYPE_BF16><<<ew_grid(npix * vecs), 256, 0, st>>>((const char*)y, y_ld, (char*)out, out_ld, npix, vecs, scale, shift);
+        bn_apply_silu_kernel<ODAMD_DTYPE_BF16><<<ew_grid(npix * vecs), 256, 0, st>>>((const char*)y, y_ld, (char*)out, out_ld, npix, vecs, scale, shift, mean);
     return (int)hipGetLastError();
 }
 
