@@ -514,11 +514,12 @@ __global__ void __launch_bounds__(256) loss_pos_kernel(LossP p) {
         float* g = p.dpred + row;
         const D4 c = ciou_d4(pr, lb);
         fa += (double)c.v;
-        for (int k = 0; k < 4; ++k) g[k] = -c.d[k] / (float)p.P;      // frame = 1 - mean(ciou)
+        // a row may be listed more than once (the reference's assignment keeps duplicates): add
+        for (int k = 0; k < 4; ++k) atomicAdd(&g[k], -c.d[k] / (float)p.P);   // frame = 1 - mean(ciou)
         if (C == 1) {                                                  // BCEWithLogitsLoss, mean over P
             const float x = pr[5], y = lb[5];
             ca += (double)(fmaxf(x, 0.0f) - x * y + log1pf(expf(-fabsf(x))));
-            g[5] = (1.0f / (1.0f + expf(-x)) - y) / (float)p.P;
+            atomicAdd(&g[5], (1.0f / (1.0f + expf(-x)) - y) / (float)p.P);
         } else {                                                       // CrossEntropyLoss with soft targets
             float m = pr[5];
             for (int k = 1; k < C; ++k) m = fmaxf(m, pr[5 + k]);
@@ -528,7 +529,7 @@ __global__ void __launch_bounds__(256) loss_pos_kernel(LossP p) {
             float l = 0.0f;
             for (int k = 0; k < C; ++k) {
                 l -= lb[5 + k] * (pr[5 + k] - lse);
-                g[5 + k] = (expf(pr[5 + k] - lse) * ts - lb[5 + k]) / (float)p.P;
+                atomicAdd(&g[5 + k], (expf(pr[5 + k] - lse) * ts - lb[5 + k]) / (float)p.P);
             }
             ca += (double)l;
         }

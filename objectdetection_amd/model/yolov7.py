@@ -28,6 +28,9 @@ class yolov7(torch.nn.Module):
         self.head1 = head(_w(self.elan_h22), self.output_size[1], self.output_class)
         self.head2 = head(_w(self.elan_h25), self.output_size[2], self.output_class)
         self._plans = {}
+        self._state = None          # FlatState, created by the first training forward
+        self._train_plans = {}
+        self._hook = None
 
     # ---- construction ------------------------------------------------------------------------
     def _build_standard(self, d, n):
@@ -179,7 +182,36 @@ class yolov7(torch.nn.Module):
         return y if x.dtype == torch.float32 else y.to(x.dtype)
 
     def forward(self, x):
+        if self.training:
+            return self.forward_train(x)
         return self._decoded(x, False)
+
+    # ---- training ------------------------------------------------------------------------------
+    def train_state(self):
+        """Flat parameter / gradient / optimizer storage; the parameters become views into it."""
+        from .. import train_engine
+        if self._state is None:
+            self._state = train_engine.FlatState(self)
+        return self._state
+
+    def train_plan(self, batch, size):
+        from .. import train_engine
+        key = (batch, size)
+        plan = self._train_plans.get(key)
+        if plan is None:
+            plan = self._train_plans[key] = train_engine.TrainPlan(self, self.train_state(), batch, size)
+        return plan
+
+    def forward_train(self, x):
+        """Train-mode forward (batch-statistics BatchNorm, running buffers updated).  The result is
+        connected to torch autograd: `loss.backward()` runs the HIP backward pass and leaves the
+        gradients in `param.grad` (views of the flat gradient buffer)."""
+        if not x.is_cuda:
+            raise RuntimeError('objectdetection_amd runs on the GPU only (no CPU fallback)')
+        if self._hook is None:
+            self._hook = torch.zeros(1, device=x.device, requires_grad=True)
+        plan = self.train_plan(x.shape[0], x.shape[2])
+        return _TrainForward.apply(x.detach().float().contiguous(), self._hook, plan)
 
     def forward_deploy(self, x):
         """forward + sigmoid on channels 4: (what `deploy(model)(x)` returns)."""
@@ -188,4 +220,26 @@ class yolov7(torch.nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state['_plans'] = {}
+        state['_train_plans'] = {}
+        state['_state'] = None
+        state['_hook'] = None
         return state
+
+
+class _TrainForward(torch.autograd.Function):
+    """Autograd node of the whole train-mode forward: backward replays the reverse plan."""
+
+    @staticmethod
+    def forward(ctx, x, hook, plan):
+        ctx.plan, ctx.x = plan, x
+        pred = plan.forward(x)
+        pred._odamd_plan = plan
+        return pred
+
+    @staticmethod
+    def backward(ctx, grad_pred):
+        plan = ctx.plan
+        if grad_pred.data_ptr() != plan.dpred.data_ptr():
+            plan.dpred.copy_(grad_pred)
+        plan.backward(ctx.x, reducer=getattr(plan, 'reducer', None))
+        return None, None, None

@@ -1,0 +1,328 @@
+"""Training entry, API-compatible with the reference's train_class.py for the parts on the hot
+path: train_class (model / optimizer / loss / EMA / data-parallel wiring and the step loop),
+loss_class, focal_loss (folded into loss_class), model_ema, lr_adjust, plus a synthetic dataset.
+
+Reference: train_class.py:15-51 (wiring), :158-171 (optimizer), :177-294 (loop), :397-474 (loss),
+:477-499 (EMA), :502-521 (LR).  Image decoding / augmentation (`torch_dataset.__getitem__`),
+validation metric, wandb and pruning surgery are outside this build; the label -> grid assignment
+rule (train_class.py:578-607) is restated in `assign_labels` for synthetic labels.
+
+One training step = forward (train-mode BN) -> loss (+ gradient) -> backward -> bucketed gradient
+all-reduce (RCCL, overlapped with backward) -> fused Adam + EMA; every arithmetic step is a HIP
+kernel of libodamd.so.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import train_engine as te
+from .model.layer import decode
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, plan, screen_list, label_expend, smooth):
+        out = plan.loss(screen_list, label_expend, smooth)
+        ctx.plan = plan
+        return out.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        # d(loss)/d(pred) was produced together with the loss value; only out[0] carries gradient
+        plan.dpred.mul_(g[0])      # no host read: the step stays asynchronous
+        return plan.dpred, None, None, None, None
+
+
+class loss_class:
+    """loss_class of the reference: __call__(pred, screen_list, label_expend) ->
+    (loss, frame_loss, confidence_loss, class_loss)."""
+
+    def __init__(self, args):
+        self.device = args.device
+        self.input_size = args.input_size
+        self.output_size = args.output_size
+        self.label_smooth = args.label_smooth
+
+    def __call__(self, pred, screen_list, label_expend):
+        plan = getattr(pred, '_odamd_plan', None)
+        if plan is None:
+            raise RuntimeError('loss_class needs the prediction of a training-mode objectdetection_amd yolov7')
+        out = _LossFn.apply(pred, plan, screen_list, label_expend, self.label_smooth)
+        return out[0], out[1], out[2], out[3]
+
+
+class lr_adjust:
+    """Per-step cosine decay with linear warm-up (train_class.py:502-521)."""
+
+    def __init__(self, args, step_epoch, epoch_finished):
+        self.lr_start = args.lr_start
+        self.lr_end = args.lr_end_ratio * args.lr_start
+        self.lr_end_epoch = args.lr_end_epoch
+        self.step_all = self.lr_end_epoch * step_epoch
+        self.step_finished = epoch_finished * step_epoch
+        self.warmup_step = max(5, int(args.warmup_ratio * self.step_all))
+
+    def __call__(self, optimizer):
+        self.step_finished += 1
+        lr = te.lr_schedule(self.step_finished, self.lr_start, self.lr_end, self.step_all, self.warmup_step)
+        for group in optimizer.param_groups:
+            group['lr'] = lr
+        return optimizer
+
+
+class FusedAdam:
+    """torch.optim.Adam(lr, betas=(0.937, 0.999), weight_decay) over the model's flat buffers, fused
+    with the EMA update; `step()` is one kernel launch (+ one for the EMA of the BN buffers)."""
+
+    def __init__(self, model, lr, betas=(0.937, 0.999), weight_decay=0.0, eps=1e-8):
+        self.state = model.train_state()
+        self.param_groups = [{'lr': lr, 'betas': betas, 'weight_decay': weight_decay, 'eps': eps}]
+        self.grad_scale = 1.0
+        self.ema = False
+
+    def step(self):
+        g = self.param_groups[0]
+        te.optimizer_step(self.state, g['lr'], g['weight_decay'], g['betas'], g['eps'], self.grad_scale, self.ema)
+
+    def zero_grad(self):
+        self.state.grad.zero_()
+
+    def state_dict(self):
+        s = self.state
+        return {'step': s.step, 'exp_avg': s.exp_avg.clone(), 'exp_avg_sq': s.exp_avg_sq.clone(),
+                'param_groups': [dict(g) for g in self.param_groups]}
+
+    def load_state_dict(self, d):
+        s = self.state
+        s.step = d['step']
+        s.exp_avg.copy_(d['exp_avg'])
+        s.exp_avg_sq.copy_(d['exp_avg_sq'])
+
+
+class model_ema:
+    """Exponential moving average of every floating state_dict entry (train_class.py:477-499).
+    The averages live in flat buffers updated inside the optimizer launch; `ema_model` builds a
+    module holding them on demand (saving / validation)."""
+
+    def __init__(self, model, decay=0.9999, tau=2000, update_total=0):
+        self.model = model.module if hasattr(model, 'module') else model
+        self.state = self.model.train_state()
+        self.state.enable_ema()
+        self.state.ema_updates = update_total
+
+    @property
+    def update_total(self):
+        return self.state.ema_updates
+
+    @update_total.setter
+    def update_total(self, v):
+        self.state.ema_updates = v
+
+    def update(self, model=None):
+        """No-op: the EMA is applied by FusedAdam.step() in the same launch as the parameters."""
+
+    @property
+    def ema_model(self):
+        import copy
+        st = self.state
+        twin = copy.deepcopy(self.model).eval()
+        with torch.no_grad():
+            for (n, p), (_, q) in zip(self.model.named_parameters(), twin.named_parameters()):
+                o = st.param_names[n]
+                q.copy_(st.ema_param[o:o + p.numel()].view(p.shape))
+                q.requires_grad_(False)
+            for (n, b), (_, c) in zip(self.model.named_buffers(), twin.named_buffers()):
+                if b.dtype.is_floating_point:
+                    o = st.buf_names[n]
+                    c.copy_(st.ema_buffers[o:o + b.numel()].view(b.shape))
+        return twin
+
+
+# ---------------------------------------------------------------------------------------------
+# labels
+# ---------------------------------------------------------------------------------------------
+def prediction_ranges(args):
+    """Box range every grid row can express: decode(-4) .. decode(+4) (train_class.py:537-543)."""
+    anchor = args.input_size * torch.tensor(args.anchor, dtype=torch.float32)
+    lo, hi = [], []
+    for i, hw in enumerate(args.output_size):
+        stride = args.input_size / hw
+        gy, gx = torch.meshgrid(torch.arange(hw, dtype=torch.float32), torch.arange(hw, dtype=torch.float32),
+                                indexing='ij')
+        for t, dst in ((torch.sigmoid(torch.tensor(-4.0)), lo), (torch.sigmoid(torch.tensor(4.0)), hi)):
+            rows = []
+            for a in range(args.output_layer[i]):
+                cx = (2 * t - 0.5 + gx) * stride
+                cy = (2 * t - 0.5 + gy) * stride
+                w = torch.full_like(cx, float(4 * t ** 2 * anchor[i, a, 0]))
+                h = torch.full_like(cx, float(4 * t ** 2 * anchor[i, a, 1]))
+                rows.append(torch.stack([cx, cy, w, h], -1).reshape(-1, 4))
+            dst.append(torch.cat(rows))
+    return torch.cat(lo), torch.cat(hi)
+
+
+def assign_labels(label, range_floor, range_upper):
+    """Label -> grid-row assignment exactly as train_class.py:578-607 behaves: a label matches every
+    row whose expressible (cx, cy, w, h) range strictly contains it.  The reference's conflict
+    branch never fires (its `label_set` is never filled), so a row matched by several labels appears
+    once per label in the index list and carries the LAST matching label every time; that is
+    reproduced here because the loss counts such rows once per occurrence.
+    label: (L, K) float32 rows (cx,cy,w,h,conf,cls...).  Returns (sorted row indices int64 with
+    duplicates, label rows aligned with them)."""
+    k = label.shape[1]
+    box = label[:, None, 0:4]
+    hit = ((range_floor[None] < box) & (box < range_upper[None])).all(dim=2)        # (L, R)
+    li, rows = hit.nonzero(as_tuple=True)
+    if len(rows) == 0:
+        return torch.zeros(0, dtype=torch.int64), torch.zeros((0, k), dtype=torch.float32)
+    last = torch.full((hit.shape[1],), -1, dtype=torch.int64)
+    last[rows] = li                      # nonzero() is ordered by label, so the last write wins
+    last.scatter_reduce_(0, rows, li, 'amax', include_self=True)
+    rows_sorted, _ = torch.sort(rows)
+    return rows_sorted, label[last[rows_sorted]]
+
+
+class synthetic_dataset(torch.utils.data.Dataset):
+    """Synthetic images and labels: uniform-noise images; per image `boxes` boxes with cx,cy ~
+    U(0.1 S, 0.9 S), w,h ~ U(20, 200), uniform class; labels smoothed like train_class.py:573-577."""
+
+    def __init__(self, args, length, boxes=8, seed=999):
+        self.args, self.length, self.boxes, self.seed = args, length, boxes, seed
+        self.range_floor, self.range_upper = prediction_ranges(args)
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, index):
+        a = self.args
+        g = torch.Generator().manual_seed(self.seed + index)
+        s, c, ls = a.input_size, a.output_class, a.label_smooth
+        image = torch.rand(3, s, s, generator=g)
+        frame = torch.cat([torch.rand(self.boxes, 2, generator=g) * 0.8 * s + 0.1 * s,
+                           torch.rand(self.boxes, 2, generator=g) * 180 + 20], 1)
+        cls = torch.full((self.boxes, c), ls)
+        cls[torch.arange(self.boxes), torch.randint(0, c, (self.boxes,), generator=g)] = 1 - ls
+        label = torch.cat([frame, torch.full((self.boxes, 1), 1 - ls), cls], 1).float()
+        screen, expend = assign_labels(label, self.range_floor, self.range_upper)
+        return image, screen, expend, label
+
+    @staticmethod
+    def collate_fn(items):
+        return (torch.stack([i[0] for i in items]), [i[1] for i in items], torch.cat([i[2] for i in items]),
+                [i[3] for i in items])
+
+
+# ---------------------------------------------------------------------------------------------
+# driver
+# ---------------------------------------------------------------------------------------------
+class train_class:
+    """Wiring and step loop of the reference's train_class (train_class.py:15-51, :177-294)."""
+
+    def __init__(self, args, dataloader=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('objectdetection_amd.train_class needs a GPU: there is no CPU fallback')
+        self.args = args
+        self.model_dict = self.model_load()
+        self.model_dict['model'] = self.model_dict['model'].to(args.device)
+        self.model = self.model_dict['model']
+        self.train_dataloader = dataloader if dataloader is not None else self.dataloader_load()
+        self.optimizer, self.optimizer_adjust = self.optimizer_load()
+        self.loss = loss_class(args)
+        self.ema = None
+        if args.local_rank == 0 and args.ema:
+            self.ema = model_ema(self.model)
+            self.ema.update_total = self.model_dict['ema_update']
+            self.optimizer.ema = True
+        self.reducer = None
+        if args.distributed:
+            import torch.distributed as dist
+            st = self.model.train_state()
+            # every rank starts from rank 0's parameters and buffers (DDP constructor broadcast)
+            dist.broadcast(st.param, 0)
+            dist.broadcast(st.buffers, 0)
+            self.reducer = te.GradReducer(st.grad, n_buckets=3)
+            self.optimizer.grad_scale = 1.0 / self.reducer.world
+
+    def model_load(self):
+        args = self.args
+        if os.path.exists(getattr(args, 'weight_path', '')):
+            model_dict = torch.load(args.weight_path, map_location='cpu', weights_only=False)
+            for p in model_dict['model'].parameters():
+                p.requires_grad_(True)
+            if args.weight_again:
+                model_dict.update(epoch_finished=0, optimizer_state_dict=None, ema_update=0, standard=0)
+            return model_dict
+        from .model.yolov7 import yolov7
+        return {'model': yolov7(args), 'epoch_finished': 0, 'optimizer_state_dict': None, 'ema_update': 0,
+                'standard': 0}
+
+    def dataloader_load(self):
+        args = self.args
+        n = getattr(args, 'synthetic_images', args.batch * 8)
+        ds = synthetic_dataset(args, n)
+        sampler = torch.utils.data.distributed.DistributedSampler(ds) if args.distributed else None
+        return torch.utils.data.DataLoader(ds, batch_size=args.batch, shuffle=sampler is None, drop_last=True,
+                                           sampler=sampler, collate_fn=ds.collate_fn,
+                                           num_workers=getattr(args, 'num_worker', 0))
+
+    def optimizer_load(self):
+        args = self.args
+        wd = args.r_value if args.regularization == 'L2' else 0.0
+        opt = FusedAdam(self.model, args.lr_start, (0.937, 0.999), wd)
+        if self.model_dict['optimizer_state_dict'] is not None:
+            opt.load_state_dict(self.model_dict['optimizer_state_dict'])
+        step_epoch = max(len(self.train_dataloader), 1)
+        adjust = lr_adjust(args, step_epoch, self.model_dict['epoch_finished'])
+        return adjust(opt), adjust
+
+    def train_step(self, image_batch, screen_list, label_expend):
+        """One step of train_class.py:196-218; returns the (4,) device tensor of losses (no host sync)."""
+        args = self.args
+        model = self.model
+        image_batch = image_batch.to(args.device, non_blocking=True)
+        plan = model.train_plan(image_batch.shape[0], image_batch.shape[2])
+        plan.reducer = self.reducer
+        pred = model(image_batch)
+        losses = self.loss(pred, screen_list, label_expend)
+        self.optimizer.zero_grad()
+        losses[0].backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.step()
+        self.optimizer = self.optimizer_adjust(self.optimizer)
+        return torch.stack(losses).detach()
+
+    def train(self):
+        args = self.args
+        history = []
+        for epoch in range(self.model_dict['epoch_finished'] + 1, args.epoch + 1):
+            self.model.train()
+            sums, steps = torch.zeros(4, device=args.device), 0
+            sampler = getattr(self.train_dataloader, 'sampler', None)
+            if hasattr(sampler, 'set_epoch'):
+                sampler.set_epoch(epoch)
+            for image_batch, screen_list, label_expend, _ in self.train_dataloader:
+                sums += self.train_step(image_batch, screen_list, label_expend)   # accumulated on the device
+                steps += 1
+            means = (sums / max(steps, 1)).tolist()                                # one host read per epoch
+            history.append(means)
+            if args.local_rank == 0 and getattr(args, 'print_info', True):
+                print(f'| train | epoch:{epoch} | train_loss:{means[0]:.4f} | frame_loss:{means[1]:.4f} |'
+                      f' confidence_loss:{means[2]:.4f} | class_loss:{means[3]:.4f} |'
+                      f' lr:{self.optimizer.param_groups[0]["lr"]:.6f} |')
+            if args.local_rank == 0:
+                self.model_dict['epoch_finished'] = epoch
+                self.model_dict['train_loss'] = means[0]
+                self.model_dict['ema_update'] = self.ema.update_total if self.ema else self.model_dict['ema_update']
+                save = getattr(args, 'save_path', None)
+                if save and (epoch % getattr(args, 'save_epoch', 5) == 0 or epoch == args.epoch):
+                    out = dict(self.model_dict)
+                    out['model'] = self.ema.ema_model if self.ema else self.model
+                    out['optimizer_state_dict'] = self.optimizer.state_dict()
+                    torch.save(out, save)
+            if args.distributed:
+                torch.distributed.barrier()
+        return history

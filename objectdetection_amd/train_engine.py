@@ -65,6 +65,9 @@ class FlatState:
                 for part in path:
                     mod = getattr(mod, part)
                 mod._buffers[leaf] = view
+                self.buf_offsets[id(view)] = o
+        self.param_names = {n: self.offsets[id(p)] for n, p in model.named_parameters()}
+        self.buf_names = {n: self.buf_offsets[id(b)] for n, b in model.named_buffers() if b.dtype.is_floating_point}
         self.ema_param = None
         self.ema_buffers = None
         self.step = 0

@@ -1,0 +1,103 @@
+"""train_class mirror end to end on the GPU: one epoch on synthetic data, first-step losses against
+the CPU oracle, optimizer/EMA wiring against the oracle's Adam on the GPU's own gradients."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import network, patterns, training as otrain
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(**kw):
+    a = patterns.default_args(input_size=128, output_class=5)
+    a.__dict__.update(device='cuda', batch=4, epoch=1, lr_start=0.001, lr_end_ratio=0.1, lr_end_epoch=10,
+                      warmup_ratio=0.01, regularization='L2', r_value=0.0005, ema=True, distributed=False,
+                      local_rank=0, weight_path='', weight_again=True, print_info=False, synthetic_images=8,
+                      save_path=None)
+    a.__dict__.update(kw)
+    return a
+
+
+def test_first_step_losses_and_optimizer_wiring():
+    from objectdetection_amd.train_class import train_class, synthetic_dataset
+    args = _args()
+    torch.manual_seed(3)
+    tc = train_class(args)
+    model = tc.model
+    patterns.fill_state_dict(model)          # parameters are already views of the flat buffers
+    st = model.train_state()
+    st.ema_param.copy_(st.param)
+    st.ema_buffers.copy_(st.buffers)
+    ds = synthetic_dataset(args, 8)
+    image, screen, expend, _ = ds.collate_fn([ds[i] for i in range(4)])
+    assert sum(len(s) for s in screen) > 20
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref_pred = network.yolov7_forward(sd, image, args, training=True)
+        ref = [float(v) for v in otrain.detection_loss(ref_pred, screen, expend, args.label_smooth, args.output_class)]
+    p0 = st.param.clone()
+    lr0 = tc.optimizer.param_groups[0]['lr']
+    assert lr0 == otrain.LrSchedule(0.001, 0.1, 10, 0.01, len(tc.train_dataloader)).step()
+    model.train()
+    losses = tc.train_step(image, screen, expend).cpu().numpy()
+    np.testing.assert_allclose(losses, ref, rtol=2e-3)
+    # Adam + EMA: replay the oracle's update on the gradients the GPU produced
+    g = st.grad.clone().cpu()
+    p, m, v = p0.cpu().clone(), torch.zeros_like(g), torch.zeros_like(g)
+    otrain.adam_step(p, g, m, v, 1, lr0, weight_decay=args.r_value)
+    np.testing.assert_allclose(st.param.cpu().numpy(), p.numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(st.exp_avg.cpu().numpy(), m.numpy(), rtol=1e-4, atol=1e-9)
+    d = otrain.ema_decay(1)
+    np.testing.assert_allclose(st.ema_param.cpu().numpy(), (d * p0.cpu() + (1 - d) * p).numpy(), rtol=1e-5, atol=1e-8)
+    assert tc.optimizer.param_groups[0]['lr'] != lr0      # schedule advanced for the next step
+    assert float(g.abs().sum()) > 0
+    # the reference style loop (model -> loss_class -> backward) leaves the same gradients
+    tc.optimizer.zero_grad()
+    pred = model(image.cuda())
+    tc.loss(pred, screen, expend)[0].backward()
+    assert float(st.grad.abs().sum()) > 0
+    twin = tc.ema.ema_model
+    assert not twin.training and len(twin.state_dict()) == len(model.state_dict())
+
+
+def test_one_epoch_runs_and_loss_is_finite():
+    from objectdetection_amd.train_class import train_class
+    torch.manual_seed(999)
+    tc = train_class(_args(epoch=2))
+    hist = tc.train()
+    assert len(hist) == 2 and all(np.isfinite(h).all() for h in hist)
+    assert hist[1][0] < hist[0][0] * 1.5
+
+
+def test_loss_with_duplicate_rows_accumulates_gradient():
+    """The reference's label assignment can list a grid row twice; the gradient of such a row is the
+    sum of both occurrences (autograd of an index gather)."""
+    import ctypes as C
+    from objectdetection_amd._lib import lib, check
+    b, r, k = 1, 40, 7
+    pred = patterns.wave('dup.pred', (b, r, k), 2.0)
+    pred[:, :, 0:2] = pred[:, :, 0:2] * 20 + 60
+    pred[:, :, 2:4] = pred[:, :, 2:4].abs() * 15 + 5
+    screen = [torch.tensor([3, 3, 9])]
+    lab = patterns.wave('dup.lab', (3, k), 0.45, 0.5)
+    lab[:, 0:2] = lab[:, 0:2] * 40 + 40
+    lab[:, 2:4] = lab[:, 2:4] * 30 + 6
+    lab[1] = lab[0]
+    p = pred.clone().requires_grad_(True)
+    vals = otrain.detection_loss(p, screen, lab, 0.01, 2)
+    vals[0].backward()
+    pd = pred.cuda().contiguous()
+    dp = torch.empty_like(pd)
+    out = torch.zeros(4, device='cuda')
+    ws = torch.empty(int(lib.odamd_loss_workspace_bytes()), dtype=torch.uint8, device='cuda')
+    idx = torch.tensor([3, 3, 9], dtype=torch.int32).cuda()
+    img = torch.zeros(3, dtype=torch.int32).cuda()
+    lb = lab.cuda().contiguous()
+    check(lib.odamd_detection_loss(pd.data_ptr(), dp.data_ptr(), idx.data_ptr(), img.data_ptr(), lb.data_ptr(), b, r, k,
+                                   3, 0.01, out.data_ptr(), ws.data_ptr(), ws.numel(), None))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), [float(v) for v in vals], rtol=2e-5)
+    np.testing.assert_allclose(dp.cpu().numpy(), p.grad.numpy(), rtol=1e-4, atol=1e-7)

@@ -1,0 +1,93 @@
+"""Host-side training logic on CPU: LR schedule, label assignment, synthetic data, and the bucketed
+gradient all-reduce on 2 gloo ranks."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from oracle import labels as olabels, patterns
+
+
+def test_lr_adjust_matches_reference_fixture(golden):
+    from objectdetection_amd.train_class import lr_adjust
+    g = golden('training.npz')
+    for tag, (step_epoch, lr_end_epoch, warm) in (('a', (10, 100, 0.01)), ('b', (400, 3, 0.05))):
+        a = argparse.Namespace(lr_start=0.001, lr_end_ratio=0.1, lr_end_epoch=lr_end_epoch, warmup_ratio=warm)
+        sched = lr_adjust(a, step_epoch, 0)
+
+        class _Opt:
+            param_groups = [{'lr': 0.0}]
+        opt, seq = _Opt(), []
+        for _ in range(30):
+            sched(opt)
+            seq.append(opt.param_groups[0]['lr'])
+        assert np.array_equal(np.array(seq), g[f'lr.{tag}'])
+
+
+def test_assign_labels_equals_reference_restatement():
+    from objectdetection_amd.train_class import assign_labels, prediction_ranges
+    args = patterns.default_args(input_size=320, output_class=4)
+    lo, hi = prediction_ranges(args)
+    rlo, rhi = olabels.ranges(args)
+    assert torch.allclose(lo, rlo[:, 0:4], rtol=1e-6, atol=1e-5) and torch.allclose(hi, rhi[:, 0:4], rtol=1e-6, atol=1e-5)
+    g = torch.Generator().manual_seed(5)
+    for trial in range(6):
+        n = 10
+        label = torch.cat([torch.rand(n, 2, generator=g) * 256 + 32, torch.rand(n, 2, generator=g) * 150 + 10,
+                           torch.rand(n, 5, generator=g)], 1)
+        if trial == 0:
+            label[1, 0:4] = label[0, 0:4] + 0.5          # two labels on the same rows
+        idx, exp = assign_labels(label, rlo[:, 0:4], rhi[:, 0:4])
+        ridx, rexp = olabels.assign(label, rlo[:, 0:4], rhi[:, 0:4])
+        assert torch.equal(idx, ridx)
+        assert torch.equal(exp, rexp)
+        assert len(idx) > 0
+    idx, exp = assign_labels(torch.zeros((0, 9)), rlo[:, 0:4], rhi[:, 0:4])
+    assert len(idx) == 0 and exp.shape == (0, 9)
+
+
+def test_synthetic_dataset_batches():
+    from objectdetection_amd.train_class import synthetic_dataset
+    args = patterns.default_args(input_size=160, output_class=5)
+    ds = synthetic_dataset(args, 4)
+    img, screen, expend, labels = ds.collate_fn([ds[0], ds[1]])
+    assert img.shape == (2, 3, 160, 160) and len(screen) == 2 and expend.shape[1] == 10
+    assert sum(len(s) for s in screen) == len(expend)
+    a, b = ds[1], ds[1]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])       # deterministic per index
+
+
+def _reducer_rank(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from objectdetection_amd.train_engine import GradReducer
+    n = 1003
+    flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    red = GradReducer(flat, n_buckets=3)
+    assert red.world == world and red.bounds[0][0] == 0 and red.bounds[-1][1] == n
+    assert [red.bucket_of(o) for o in (0, 334, 335, 1002)] == [0, 0, 1, 2]
+    for i in (2, 0, 1):          # buckets become ready out of order, as in a backward pass
+        red.ready(i)
+    scale = red.finish()
+    got = flat * scale
+    want = torch.arange(n, dtype=torch.float32) * sum(range(1, world + 1)) / world
+    out[rank] = bool(torch.allclose(got, want))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_all_reduce_two_ranks_gloo():
+    ctx = mp.get_context('spawn')
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_reducer_rank, args=(r, 2, 29517, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out[0] and out[1]
