@@ -36,6 +36,12 @@ def parse():
     p.add_argument('--conf', type=float, default=0.5)
     p.add_argument('--iou', type=float, default=0.5)
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--workload', default='infer', choices=['infer', 'train'],
+                   help="which leg `value` reports; the other one is reported in a sub-object")
+    p.add_argument('--train-batch', type=int, default=32, help='training images per GPU per step')
+    p.add_argument('--train-classes', type=int, default=5)
+    p.add_argument('--train-steps', type=int, default=None, help='default: --steps')
+    p.add_argument('--no-train', action='store_true', help='skip the training leg')
     return p.parse_args()
 
 
@@ -60,6 +66,56 @@ def cpu_baseline(model, a, margs, x_cpu):
                       f'decode/NMS of 1 image on 1 core ({t_post:.2f} s, {len(kept)} kept); reference loop is '
                       'single-threaded Python (predict.py:86-90)',
             'forward_ms_per_image': t_fwd * 1e3, 'postprocess_s_per_image': t_post}
+
+
+def train_leg(a, dev, rank, world, dist, steps, warmup):
+    """Training step (configs[2]/[3]): forward (batch-statistics BN) + loss + backward + bucketed
+    gradient all-reduce (RCCL when world > 1) + fused Adam/EMA, float32, `--train-batch` synthetic
+    images per GPU with 8 synthetic boxes each.  Weak scaling: global batch = world * train-batch."""
+    from objectdetection_amd.train_class import train_class, synthetic_dataset
+    from oracle import patterns
+    targs = patterns.default_args(input_size=a.size, output_class=a.train_classes)
+    targs.__dict__.update(device=f'cuda:{dev.index}', batch=a.train_batch, epoch=1, lr_start=0.001, lr_end_ratio=0.1,
+                          lr_end_epoch=100, warmup_ratio=0.01, regularization='L2', r_value=0.0005, ema=True,
+                          distributed=world > 1, local_rank=rank, weight_path='', weight_again=True,
+                          print_info=False, save_path=None)
+    torch.manual_seed(999)
+    ds = synthetic_dataset(targs, a.train_batch * world, seed=999)
+    batch = ds.collate_fn([ds[rank * a.train_batch + i] for i in range(a.train_batch)])
+    tc = train_class(targs, dataloader=[batch] * 1000)
+    tc.optimizer.ema = True                      # every rank carries the EMA so that ranks do equal work
+    tc.model.train_state().enable_ema()
+    tc.model.train()
+    image = batch[0].to(dev)
+    screen, expend = batch[1], batch[2]
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    first = None
+    for i in range(warmup):
+        l = tc.train_step(image, screen, expend)
+        if first is None:
+            first = l.tolist()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        l = tc.train_step(image, screen, expend)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    last = l.tolist()
+    return {'images_per_sec': world * a.train_batch * steps / dt, 'ms_per_step': dt / steps * 1e3,
+            'global_batch': world * a.train_batch, 'dtype': 'f32', 'classes': a.train_classes, 'steps': steps,
+            'parallelism': f'dp{world}' + (' (RCCL all-reduce, 3 buckets behind backward)' if world > 1 else ''),
+            'positives_per_step': int(sum(len(s) for s in screen)),
+            'loss_first': first, 'loss_last': last, 'params': tc.model.train_state().n}, tc
 
 
 def main():
@@ -167,6 +223,35 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(model, a, margs, x_cpu)
+
+    if not a.no_train:
+        # The training leg must never cost the inference line: if a collective stalls, rank 0 prints
+        # what it has and every rank leaves.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out['train'] = {'error': 'training leg did not finish within 240 s'}
+                print(json.dumps(out), flush=True)
+            os._exit(0 if rank == 0 else 1)
+        guard = threading.Timer(240.0, bail)
+        guard.daemon = True
+        guard.start()
+        del model, x
+        tsteps = a.train_steps if a.train_steps is not None else a.steps
+        train, _ = train_leg(a, dev, rank, world, dist, tsteps, max(a.warmup, 2))
+        guard.cancel()
+        if rank == 0:
+            out['train'] = train
+            if a.workload == 'train':
+                infer = {k: out[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config')}
+                out.update({'metric': 'images/sec @640^2 training step (fwd + loss + bwd + all-reduce + Adam/EMA)',
+                            'value': train['images_per_sec'], 'ms_per_step': train['ms_per_step'], 'dtype': 'f32',
+                            'steps': tsteps,
+                            'config': {'workload': f'YOLOv7-s {a.size}x{a.size} training step, batch {a.train_batch} per GPU, '
+                                                   f'synthetic labels (BASELINE configs[2]/[3]); C={a.train_classes}',
+                                       'global_batch': train['global_batch'], 'parallelism': train['parallelism']},
+                            'infer': infer})
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -209,10 +209,13 @@ int odamd_upsample2_backward(const void* dy, int dy_ld, void* dx, int dx_ld, int
                              int dtype, void* stream);
 
 /* Weight gradient of a convolution (autograd of cbs.conv / head.output): dw (cout, cin, k, k) float32
- * in the reference's parameter layout, ADDED to (float atomics).  x: (B,H,W) NHWC input, dy: NHWC
- * gradient of the raw output.  dtype float32 only in this version. */
+ * in the reference's parameter layout, ADDED to.  x: (B,H,W) NHWC input, dy: NHWC gradient of the
+ * raw output.  Workgroups store partial sums to `workspace` (odamd_conv_wgrad_workspace_bytes of the
+ * same shape) and a second launch folds them into dw in a fixed order: no atomics, the result is
+ * reproducible run to run.  dtype float32 only in this version. */
+size_t odamd_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int ksize, int stride);
 int odamd_conv_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int batch, int h, int w, int cin,
-                     int cout, int ksize, int stride, int dtype, void* stream);
+                     int cout, int ksize, int stride, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* loss_class.__call__ (train_class.py:410-427) with focal objectness (:463-474), CIoU (:449-460)
  * and BCE / soft-target cross-entropy class loss (:405-408): out4 = {loss, frame, confidence,

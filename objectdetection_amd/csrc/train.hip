@@ -122,13 +122,32 @@ channel_reduce_kernel(const char* __restrict__ y, int y_ld, const char* __restri
 
 // BN statistics finalize (model/layer.py:9,14 in train mode): batch mean / biased variance, running
 // buffers updated with momentum and the unbiased variance, affine folded to (scale, shift).
-__global__ void bn_stats_finalize_kernel(const double* __restrict__ part, int nblk, int C, double npix, const float* gamma,
-                                         const float* beta, float eps, float momentum, float* running_mean,
-                                         float* running_var, float* mean, float* invstd, float* scale, float* shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per channel: the lanes stride over the partial blocks and a butterfly of double adds
+// folds them (fixed order: the result does not depend on scheduling).
+__device__ __forceinline__ void fold_partials(const double* __restrict__ part, int nblk, int C, int c, double& s, double& q,
+                                              bool second) {
+    const int lane = threadIdx.x & 63;
+    s = 0.0; q = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+        s += part[((size_t)b * 2) * C + c];
+        if (second) q += part[((size_t)b * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s += __shfl_xor(s, m);
+        if (second) q += __shfl_xor(q, m);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+bn_stats_finalize_kernel(const double* __restrict__ part, int nblk, int C, double npix, const float* gamma,
+                         const float* beta, float eps, float momentum, float* running_mean,
+                         float* running_var, float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
+    double s, q;
+    fold_partials(part, nblk, C, c, s, q, true);
+    if ((threadIdx.x & 63) != 0) return;
     const double md = s / npix;                    // mean of (y - pivot)
     double var = q / npix - md * md;
     if (var < 0.0) var = 0.0;
@@ -148,23 +167,27 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ part, int nb
 
 // Backward finalize: dgamma, dbeta (accumulated into the parameter gradients) and the two
 // per-channel means the apply pass needs.
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, int C, double npix, float* dgamma,
-                                       float* dbeta, float* mean_dz, float* mean_dzx) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, int C, double npix, float* dgamma,
+                       float* dbeta, float* mean_dz, float* mean_dzx) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
+    double s, q;
+    fold_partials(part, nblk, C, c, s, q, true);
+    if ((threadIdx.x & 63) != 0) return;
     dbeta[c] += (float)s;
     dgamma[c] += (float)q;
     mean_dz[c] = (float)(s / npix);
     mean_dzx[c] = (float)(q / npix);
 }
 
-__global__ void bias_grad_finalize_kernel(const double* __restrict__ part, int nblk, int C, float* dbias) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256)
+bias_grad_finalize_kernel(const double* __restrict__ part, int nblk, int C, float* dbias) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += part[((size_t)b * 2) * C + c];
+    double s, q;
+    fold_partials(part, nblk, C, c, s, q, false);
+    if ((threadIdx.x & 63) != 0) return;
     dbias[c] += (float)s;
 }
 
@@ -306,32 +329,52 @@ upsample2_bwd_kernel(const char* __restrict__ dy, int dy_ld, char* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // Convolution weight gradient, float32 on v_mfma_f32_32x32x2_f32:
 //   dW[co][ci][ky][kx] = sum_pixels dY[pixel][co] * X[pixel*stride - pad + (ky,kx)][ci]
-// GEMM view: M = 32 output channels, N = 32 input channels (per tap), K = pixels.  A workgroup owns
-// one (co block, ci block) pair and a range of pixel patches; per patch it stages the dY patch
-// [pixels][32 co] and the X halo patch [pixels][32 ci] in LDS (rows of 128 bytes: a fragment read
-// is 32 consecutive floats, conflict free), accumulates in registers across all its patches and
-// finishes with one atomic add per element.  KS == 3: wave w takes taps w, w+4, w+8 over all
-// pixels of the patch; KS == 1: the four waves split the pixels.
+// GEMM view: M = output channels, N = input channels (per tap), K = pixels.  A workgroup owns one
+// (co tile, ci tile) pair and every nsplit-th pixel patch; per patch it stages the dY patch
+// [pixels][CO_T] and the X halo patch [halo pixels][CI_T] in LDS (a fragment read is 32 consecutive
+// floats: conflict free) and accumulates all taps in registers.  The four waves are laid out
+// WCO x WCI over the tile and, when the tile is smaller than four waves, WPX ways over the pixels of
+// a patch.  Each wave keeps R x R MFMA tiles per tap.
+// Every wave stores its sums to its own slice of `part` ([split][pixel group][Cout][Cin][taps], the torch
+// weight layout) and a second kernel folds the slices into dW in a fixed order: no atomics, the
+// result is reproducible.  Workgroup ids are laid out so that the pairs of one split (which read the
+// same patches) run on the same XCD and share its L2.
 // ------------------------------------------------------------------------------------------
 struct WgradP {
-    const float* x; const float* dy; float* dw;
+    const float* x; const float* dy; float* part;
     int B, H, W, Ho, Wo, Cin, Cout, x_ld, dy_ld;
-    int TH, TW, tiles_x, tiles_y, IH, IW, nsplit, ntiles, ncin;
+    int TH, TW, npix, tiles_x, tiles_y, IH, IW, nsplit, ntiles, ncin, npairs;
+    size_t slice;
 };
 
-template <int KS, int ST>
+template <int KS, int ST, int WCO, int WCI, int R>
 __global__ void __launch_bounds__(256) conv_wgrad_f32_kernel(WgradP p) {
     constexpr int TAPS = KS * KS, PAD = (KS - 1) / 2;
-    constexpr int NACC = KS == 1 ? 1 : 3;
+    constexpr int CO_T = 32 * WCO * R, CI_T = 32 * WCI * R, WPX = 4 / (WCO * WCI);
+    constexpr int NACC = TAPS * R * R;
+    constexpr int PCO = CO_T / 4, PCI = CI_T / 4;          // float4 per staged pixel
     extern __shared__ __attribute__((aligned(16))) float wl[];
-    const int npix = p.TH * p.TW;
-    float* dyl = wl;                                  // [npix][32]
-    float* xl = wl + (size_t)npix * 32;               // [IH*IW][32]
+    const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+    const int pair = slot % p.npairs, split = (slot / p.npairs) * 8 + xcd;
+    if (split >= p.nsplit) return;                          // whole workgroup leaves together
+    const int npix = p.npix, nhalo = p.IH * p.IW;
+    float* dyl = wl;                                        // [npix][CO_T]
+    float* xl = wl + (size_t)npix * CO_T;                   // [IH*IW][CI_T]
+    int* tab = (int*)(xl + (size_t)nhalo * CI_T);           // [npix] halo offset of tap (0,0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, kk = lane >> 5;
-    const int cb = blockIdx.y / p.ncin, ib = blockIdx.y % p.ncin;
-    const int co0 = cb * 32, ci0 = ib * 32;
-    const int nco = min(32, p.Cout - co0), nci = min(32, p.Cin - ci0);
+    const int wco = wave % WCO, wci = (wave / WCO) % WCI, wpx = wave / (WCO * WCI);
+    const int cb = pair / p.ncin, ib = pair % p.ncin;
+    const int co0 = cb * CO_T, ci0 = ib * CI_T;
+    const int nco = min(CO_T, p.Cout - co0), nci = min(CI_T, p.Cin - ci0);
+
+    for (int q = tid; q < npix; q += 256) {
+        const int ty = q / p.TW, tx = q - ty * p.TW;
+        tab[q] = ty < p.TH ? ((ty * ST) * p.IW + tx * ST) * CI_T : 0;
+    }
+    int tapoff[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) tapoff[t] = ((t / KS) * p.IW + (t % KS)) * CI_T;
 
     f32x16_t acc[NACC];
 #pragma unroll
@@ -339,71 +382,92 @@ __global__ void __launch_bounds__(256) conv_wgrad_f32_kernel(WgradP p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][e] = 0.0f;
 
-    for (int t = blockIdx.x; t < p.ntiles; t += p.nsplit) {
+    const int steps = npix >> 1;
+    const int s0 = wpx * (steps / WPX), s1 = s0 + steps / WPX;
+    for (int t = split; t < p.ntiles; t += p.nsplit) {
         const int b = t / (p.tiles_x * p.tiles_y), tt = t % (p.tiles_x * p.tiles_y);
         const int oy0 = (tt / p.tiles_x) * p.TH, ox0 = (tt % p.tiles_x) * p.TW;
         __syncthreads();
-        // dY patch: 8 float4 per pixel
-        for (int i = tid; i < npix * 8; i += 256) {
-            const int pix = i >> 3, part = i & 7;
-            const int oy = oy0 + pix / p.TW, ox = ox0 + pix % p.TW;
+        for (int i = tid; i < npix * PCO; i += 256) {
+            const int pix = i / PCO, part = i % PCO;
+            const int ty = pix / p.TW, tx = pix - ty * p.TW;
+            const int oy = oy0 + ty, ox = ox0 + tx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oy < p.Ho && ox < p.Wo) {
+            if (ty < p.TH && oy < p.Ho && ox < p.Wo && part * 4 < nco) {
                 const float* s = p.dy + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0 + part * 4;
                 if (part * 4 + 4 <= nco) v = *(const float4*)s;
-                else { float* f = (float*)&v; for (int e = 0; part * 4 + e < nco; ++e) f[e] = s[e]; }
+                else { v.x = s[0]; if (part * 4 + 1 < nco) v.y = s[1]; if (part * 4 + 2 < nco) v.z = s[2]; }
             }
-            *(float4*)(dyl + pix * 32 + part * 4) = v;
+            *(float4*)(dyl + pix * CO_T + part * 4) = v;
         }
-        // X halo patch
         const int iy0 = oy0 * ST - PAD, ix0 = ox0 * ST - PAD;
-        for (int i = tid; i < p.IH * p.IW * 8; i += 256) {
-            const int pix = i >> 3, part = i & 7;
-            const int gy = iy0 + pix / p.IW, gx = ix0 + pix % p.IW;
+        for (int i = tid; i < nhalo * PCI; i += 256) {
+            const int pix = i / PCI, part = i % PCI;
+            const int hy = pix / p.IW;
+            const int gy = iy0 + hy, gx = ix0 + pix - hy * p.IW;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && part * 4 < nci) {
                 const float* s = p.x + (((size_t)b * p.H + gy) * p.W + gx) * p.x_ld + ci0 + part * 4;
                 if (part * 4 + 4 <= nci) v = *(const float4*)s;
-                else { float* f = (float*)&v; for (int e = 0; part * 4 + e < nci; ++e) f[e] = s[e]; }
+                else { v.x = s[0]; if (part * 4 + 1 < nci) v.y = s[1]; if (part * 4 + 2 < nci) v.z = s[2]; }
             }
-            *(float4*)(xl + pix * 32 + part * 4) = v;
+            *(float4*)(xl + pix * CI_T + part * 4) = v;
         }
         __syncthreads();
-        if (KS == 1) {
-            const int q0 = wave * (npix / 4), q1 = q0 + npix / 4;
-            for (int q = q0 + kk; q < q1; q += 2) {
-                const int ty = q / p.TW, tx = q - ty * p.TW;
-                const float a = dyl[q * 32 + col];
-                const float bv = xl[((ty * ST) * p.IW + tx * ST) * 32 + col];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[0], 0, 0, 0);
-            }
-        } else {
-            for (int q = kk; q < npix; q += 2) {
-                const int ty = q / p.TW, tx = q - ty * p.TW;
-                const float a = dyl[q * 32 + col];
-                const int base = ((ty * ST) * p.IW + tx * ST) * 32 + col;
+#pragma unroll 2
+        for (int s = s0; s < s1; ++s) {
+            const int q = 2 * s + kk;
+            const float* ap = dyl + q * CO_T + wco * R * 32 + col;
+            const float* bp = xl + tab[q] + wci * R * 32 + col;
+            float a[R];
 #pragma unroll
-                for (int j = 0; j < NACC; ++j) {
-                    const int tap = wave + 4 * j;
-                    if (tap < TAPS) {
-                        const float bv = xl[base + ((tap / KS) * p.IW + (tap % KS)) * 32];
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[j], 0, 0, 0);
-                    }
+            for (int r = 0; r < R; ++r) a[r] = ap[r * 32];
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                for (int rc = 0; rc < R; ++rc) {
+                    const float bv = bp[tapoff[tp] + rc * 32];
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        acc[(tp * R + r) * R + rc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], bv, acc[(tp * R + r) * R + rc], 0, 0, 0);
                 }
-            }
         }
     }
     // D[row = co][col = ci]: lane holds col = lane&31, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
+    float* out = p.part + ((size_t)split * WPX + wpx) * p.slice;    // one slice per pixel group
 #pragma unroll
-    for (int j = 0; j < NACC; ++j) {
-        const int tap = KS == 1 ? 0 : wave + 4 * j;
-        if (tap >= TAPS) continue;
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int co = (e & 3) + 8 * (e >> 2) + 4 * kk, ci = col;
-            if (co < nco && ci < nci)
-                atomicAdd(&p.dw[((size_t)(co0 + co) * p.Cin + ci0 + ci) * TAPS + tap], acc[j][e]);
+        for (int rc = 0; rc < R; ++rc) {
+            const int ci = ci0 + (wci * R + rc) * 32 + col;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + (wco * R + r) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                if (co < p.Cout && ci < p.Cin) {
+                    float* o = out + ((size_t)co * p.Cin + ci) * TAPS;
+#pragma unroll
+                    for (int tp = 0; tp < TAPS; ++tp) o[tp] = acc[(tp * R + r) * R + rc][e];
+                }
+            }
         }
+}
+
+// dw[i] += sum over slices (fixed order).  Workgroup: 32 elements x 8 slice groups.
+__global__ void __launch_bounds__(256) wgrad_fold_kernel(const float* __restrict__ part, size_t slice, int nslices,
+                                                         float* __restrict__ dw) {
+    __shared__ float red[8][32];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const size_t i = (size_t)blockIdx.x * 32 + e;
+    float s = 0.f;
+    if (i < slice)
+        for (int k = g; k < nslices; k += 8) s += part[(size_t)k * slice + i];
+    red[g][e] = s;
+    __syncthreads();
+    if (g == 0 && i < slice) {
+        float t = red[0][e];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][e];
+        dw[i] += t;
     }
 }
 
@@ -642,6 +706,88 @@ int ew_grid(size_t n) {
 
 }  // namespace
 
+namespace {
+struct WgradPlan {
+    WgradP p;
+    int wco, wci, r;
+    size_t lds;
+    int grid, nslices;
+};
+
+// Tile shape, patch shape and split count of one weight-gradient launch.
+int wgrad_plan(int batch, int h, int w, int cin, int cout, int ksize, int stride, WgradPlan& o) {
+    if (batch < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return ODAMD_E_ARG;
+    if (!((ksize == 1 && stride == 1) || (ksize == 3 && (stride == 1 || stride == 2)))) return ODAMD_E_ARG;
+    WgradP& p = o.p;
+    p = {};
+    p.B = batch; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout;
+    const int pad = (ksize - 1) / 2, taps = ksize * ksize;
+    p.Ho = (h + 2 * pad - ksize) / stride + 1;
+    p.Wo = (w + 2 * pad - ksize) / stride + 1;
+    if (ksize == 3) { o.r = 1; o.wco = cout > 32 ? 2 : 1; o.wci = cin > 32 ? 2 : 1; }
+    else if (cout <= 32 && cin <= 32) { o.r = 1; o.wco = 1; o.wci = 1; }
+    else { o.r = 2; o.wco = cout > 64 ? 2 : 1; o.wci = cin > 64 ? 2 : 1; }
+    const int co_t = 32 * o.wco * o.r, ci_t = 32 * o.wci * o.r;
+    // patch width: the largest divisor of the row length in [8, 40], else 32 with guarded edges
+    p.TW = 0;
+    for (int d = p.Wo < 40 ? p.Wo : 40; d >= 8; --d)
+        if (p.Wo % d == 0) { p.TW = d; break; }
+    if (p.TW == 0) p.TW = p.Wo < 32 ? p.Wo : 32;
+    // patch height: as many rows as keep the staging under 64 KB (two workgroups per CU), at most 128 pixels
+    for (p.TH = (128 / p.TW > 1 ? 128 / p.TW : 1);; --p.TH) {
+        p.npix = (p.TH * p.TW + 7) & ~7;
+        p.IH = (p.TH - 1) * stride + ksize;
+        p.IW = (p.TW - 1) * stride + ksize;
+        o.lds = ((size_t)p.npix * co_t + (size_t)p.IH * p.IW * ci_t) * sizeof(float) + (size_t)p.npix * sizeof(int);
+        if (o.lds <= 64 * 1024 || p.TH == 1) break;
+    }
+    if (p.TH > p.Ho) {
+        p.TH = p.Ho;
+        p.npix = (p.TH * p.TW + 7) & ~7;
+        p.IH = (p.TH - 1) * stride + ksize;
+        o.lds = ((size_t)p.npix * co_t + (size_t)p.IH * p.IW * ci_t) * sizeof(float) + (size_t)p.npix * sizeof(int);
+    }
+    if (o.lds > 160 * 1024) return ODAMD_E_SHAPE;
+    p.tiles_x = (p.Wo + p.TW - 1) / p.TW;
+    p.tiles_y = (p.Ho + p.TH - 1) / p.TH;
+    p.ntiles = batch * p.tiles_x * p.tiles_y;
+    p.ncin = (cin + ci_t - 1) / ci_t;
+    p.npairs = p.ncin * ((cout + co_t - 1) / co_t);
+    int nsplit = (512 + p.npairs - 1) / p.npairs;          // about two workgroups per CU
+    nsplit = (nsplit + 7) & ~7;
+    if (nsplit > p.ntiles) nsplit = p.ntiles;
+    p.nsplit = nsplit;
+    p.slice = (size_t)cout * cin * taps;
+    o.grid = 8 * p.npairs * ((nsplit + 7) / 8);
+    o.nslices = nsplit * (4 / (o.wco * o.wci));
+    return ODAMD_OK;
+}
+
+template <int KS, int ST>
+void wgrad_launch(const WgradPlan& o, hipStream_t st) {
+    const int key = o.wco * 100 + o.wci * 10 + o.r;
+#define ODAMD_WG(WCO, WCI, R)                                                                                     \
+    case WCO * 100 + WCI * 10 + R: {                                                                              \
+        auto k = conv_wgrad_f32_kernel<KS, ST, WCO, WCI, R>;                                                      \
+        if (o.lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o.lds); \
+        k<<<o.grid, 256, o.lds, st>>>(o.p);                                                                       \
+        break;                                                                                                    \
+    }
+    switch (key) {
+        ODAMD_WG(1, 1, 1) ODAMD_WG(2, 1, 1) ODAMD_WG(1, 2, 1) ODAMD_WG(2, 2, 1)
+        default:
+            if constexpr (KS == 1) {
+                switch (key) {
+                    ODAMD_WG(1, 1, 2) ODAMD_WG(2, 1, 2) ODAMD_WG(1, 2, 2) ODAMD_WG(2, 2, 2)
+                    default: break;
+                }
+            }
+            break;
+    }
+#undef ODAMD_WG
+}
+}  // namespace
+
 extern "C" {
 
 size_t odamd_bn_workspace_bytes(int channels) { return ((size_t)RED_MAX_BLOCKS * 2 + 1) * channels * sizeof(double); }
@@ -665,7 +811,7 @@ int odamd_bn_train_forward(const void* y, int y_ld, void* out, int out_ld, size_
         channel_reduce_kernel<ODAMD_DTYPE_F32, 0><<<nblk, vecs * rows, lds, st>>>((const char*)y, y_ld, nullptr, 0, npix, channels, vecs, rows, nullptr, nullptr, nullptr, nullptr, part);
     else
         channel_reduce_kernel<ODAMD_DTYPE_BF16, 0><<<nblk, vecs * rows, lds, st>>>((const char*)y, y_ld, nullptr, 0, npix, channels, vecs, rows, nullptr, nullptr, nullptr, nullptr, part);
-    bn_stats_finalize_kernel<<<(channels + 63) / 64, 64, 0, st>>>(part, nblk, channels, (double)npix, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+    bn_stats_finalize_kernel<<<(channels + 3) / 4, 256, 0, st>>>(part, nblk, channels, (double)npix, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
     if (dtype == ODAMD_DTYPE_F32)
         bn_apply_silu_kernel<ODAMD_DTYPE_F32><<<ew_grid(npix * vecs), 256, 0, st>>>((const char*)y, y_ld, (char*)out, out_ld, npix, vecs, scale, shift, mean);
     else
@@ -692,7 +838,7 @@ int odamd_bn_silu_backward(void* y_dy, int y_ld, const void* dact, int dact_ld, 
         channel_reduce_kernel<ODAMD_DTYPE_F32, 1><<<nblk, vecs * rows, lds, st>>>((const char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, channels, vecs, rows, scale, shift, mean, invstd, part);
     else
         channel_reduce_kernel<ODAMD_DTYPE_BF16, 1><<<nblk, vecs * rows, lds, st>>>((const char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, channels, vecs, rows, scale, shift, mean, invstd, part);
-    bn_bwd_finalize_kernel<<<(channels + 63) / 64, 64, 0, st>>>(part, nblk, channels, (double)npix, dgamma, dbeta, mean_dz, mean_dzx);
+    bn_bwd_finalize_kernel<<<(channels + 3) / 4, 256, 0, st>>>(part, nblk, channels, (double)npix, dgamma, dbeta, mean_dz, mean_dzx);
     if (dtype == ODAMD_DTYPE_F32)
         bn_bwd_apply_kernel<ODAMD_DTYPE_F32><<<ew_grid(npix * vecs), 256, 0, st>>>((char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, vecs, scale, shift, mean, invstd, mean_dz, mean_dzx);
     else
@@ -717,7 +863,7 @@ int odamd_bias_grad(const void* dy, int dy_ld, size_t npix, int channels, float*
         channel_reduce_kernel<ODAMD_DTYPE_BF16, 2><<<nblk, vecs * rows, lds, st>>>((const char*)dy, dy_ld, nullptr, 0, npix, channels, vecs, rows, nullptr, nullptr, nullptr, nullptr, part);
     else
         return ODAMD_E_ARG;
-    bias_grad_finalize_kernel<<<(channels + 63) / 64, 64, 0, st>>>(part, nblk, channels, dbias);
+    bias_grad_finalize_kernel<<<(channels + 3) / 4, 256, 0, st>>>(part, nblk, channels, dbias);
     return (int)hipGetLastError();
 }
 
@@ -758,40 +904,30 @@ int odamd_upsample2_backward(const void* dy, int dy_ld, void* dx, int dx_ld, int
     return (int)hipGetLastError();
 }
 
+size_t odamd_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int ksize, int stride) {
+    WgradPlan o;
+    if (wgrad_plan(batch, h, w, cin, cout, ksize, stride, o) != ODAMD_OK) return 0;
+    return (size_t)o.nslices * o.p.slice * sizeof(float);
+}
+
 int odamd_conv_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int batch, int h, int w, int cin,
-                     int cout, int ksize, int stride, int dtype, void* stream) {
-    if (!x || !dy || !dw || batch < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return ODAMD_E_ARG;
+                     int cout, int ksize, int stride, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !dy || !dw || !workspace) return ODAMD_E_ARG;
     if (dtype != ODAMD_DTYPE_F32) return ODAMD_E_ARG;   // bf16 activations: not built yet
-    if (!((ksize == 1 && stride == 1) || (ksize == 3 && (stride == 1 || stride == 2)))) return ODAMD_E_ARG;
-    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || (x_ld & 3) || (dy_ld & 3)) return ODAMD_E_ALIGN;
-    WgradP p = {};
-    p.x = (const float*)x; p.dy = (const float*)dy; p.dw = dw;
-    p.B = batch; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout; p.x_ld = x_ld; p.dy_ld = dy_ld;
-    const int pad = (ksize - 1) / 2;
-    p.Ho = (h + 2 * pad - ksize) / stride + 1;
-    p.Wo = (w + 2 * pad - ksize) / stride + 1;
-    // output patch: 128 pixels (64 for stride 2), TW = 32 or the width if smaller
-    const int npix_t = stride == 2 ? 64 : 128;
-    p.TW = p.Wo < 32 ? (p.Wo >= 16 ? 16 : 8) : 32;
-    if (p.Wo == 20 || p.Wo == 40) p.TW = p.Wo == 20 ? 16 : 32;
-    p.TH = npix_t / p.TW;
-    p.tiles_x = (p.Wo + p.TW - 1) / p.TW;
-    p.tiles_y = (p.Ho + p.TH - 1) / p.TH;
-    p.IH = (p.TH - 1) * stride + ksize;
-    p.IW = (p.TW - 1) * stride + ksize;
-    p.ntiles = batch * p.tiles_x * p.tiles_y;
-    p.ncin = (cin + 31) / 32;
-    const int ncout = (cout + 31) / 32;
-    int nsplit = 2048 / (p.ncin * ncout);
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > p.ntiles) nsplit = p.ntiles;
-    p.nsplit = nsplit;
-    const size_t lds = ((size_t)p.TH * p.TW + (size_t)p.IH * p.IW) * 32 * sizeof(float);
-    dim3 grid(nsplit, p.ncin * ncout);
+    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)workspace & 15) || (x_ld & 3) || (dy_ld & 3)) return ODAMD_E_ALIGN;
+    WgradPlan o;
+    const int rc = wgrad_plan(batch, h, w, cin, cout, ksize, stride, o);
+    if (rc != ODAMD_OK) return rc;
+    if (workspace_bytes < (size_t)o.nslices * o.p.slice * sizeof(float)) return ODAMD_E_WORKSPACE;
+    o.p.x = (const float*)x; o.p.dy = (const float*)dy; o.p.part = (float*)workspace;
+    o.p.x_ld = x_ld; o.p.dy_ld = dy_ld;
     hipStream_t st = (hipStream_t)stream;
-    if (ksize == 1) conv_wgrad_f32_kernel<1, 1><<<grid, 256, lds, st>>>(p);
-    else if (stride == 1) conv_wgrad_f32_kernel<3, 1><<<grid, 256, lds, st>>>(p);
-    else conv_wgrad_f32_kernel<3, 2><<<grid, 256, lds, st>>>(p);
+    if (ksize == 1) wgrad_launch<1, 1>(o, st);
+    else if (stride == 1) wgrad_launch<3, 1>(o, st);
+    else wgrad_launch<3, 2>(o, st);
+    int err = (int)hipGetLastError();
+    if (err) return err;
+    wgrad_fold_kernel<<<(unsigned)((o.p.slice + 31) / 32), 256, 0, st>>>(o.p.part, o.p.slice, o.nslices, dw);
     return (int)hipGetLastError();
 }
 

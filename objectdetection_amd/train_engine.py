@@ -68,6 +68,19 @@ class FlatState:
                 self.buf_offsets[id(view)] = o
         self.param_names = {n: self.offsets[id(p)] for n, p in model.named_parameters()}
         self.buf_names = {n: self.buf_offsets[id(b)] for n, b in model.named_buffers() if b.dtype.is_floating_point}
+        # integer buffers (BatchNorm2d.num_batches_tracked) become views of one counter vector, so a
+        # train-mode forward advances all of them with one add
+        ints = [(n, b) for n, b in model.named_buffers() if not b.dtype.is_floating_point]
+        self.counters = torch.zeros(max(len(ints), 1), dtype=torch.int64, device=dev)
+        with torch.no_grad():
+            for i, (name, b) in enumerate(ints):
+                view = self.counters[i:i + 1].view(b.shape)
+                view.copy_(b)
+                mod = model
+                *path, leaf = name.split('.')
+                for part in path:
+                    mod = getattr(mod, part)
+                mod._buffers[leaf] = view
         self.ema_param = None
         self.ema_buffers = None
         self.step = 0
@@ -367,6 +380,15 @@ class TrainPlan:
                 bwd.append((lib.odamd_upsample2_backward,
                             [self._gptr(y), self._ld(y), self._gptr(x), self._ld(x), B, x.h, x.w, x.cphys, self.dtype],
                             'upsample2_bwd', None))
+        # one workspace for the partial sums of every weight-gradient launch (they run one at a time)
+        need = 16
+        for fn, args, name, _ in bwd:
+            if name == 'wgrad':
+                need = max(need, int(lib.odamd_conv_wgrad_workspace_bytes(*args[5:12])))
+        self.wgrad_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        for fn, args, name, _ in bwd:
+            if name == 'wgrad':
+                args.extend([self.wgrad_ws.data_ptr(), need])
         self.bwd = bwd
         # scratch for the head bias gradient (padded channel count), added to the real slot afterwards
         self.bias_tmp = {}
@@ -403,9 +425,7 @@ class TrainPlan:
             if slot is not None:
                 args[slot] = img
             check(fn(*args, stream), name)
-        for m in self.model.modules():
-            if isinstance(m, torch.nn.BatchNorm2d):
-                m.num_batches_tracked += 1
+        self.state.counters.add_(1)          # every BatchNorm2d.num_batches_tracked (views of this vector)
         if self.block:
             return self.out_nchw
         k = 5 + self.model.output_class

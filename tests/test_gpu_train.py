@@ -191,3 +191,44 @@ def test_whole_network_train_step_matches_reference(te, golden, tag, size, ncls,
     worst_gpu = max(rel_err(p.grad.cpu().numpy(), g64[n]) for n, p in params.items())
     print(tag, 'all parameters: worst gpu gradient error vs f64', worst_gpu, ' worst reference norm error', worst_ref)
     assert worst_gpu <= 10 * worst_ref + 1e-4
+
+
+@pytest.mark.parametrize('cin,cout,k,s,h,w,b', [
+    (3, 16, 3, 1, 32, 32, 2), (32, 32, 3, 1, 20, 20, 3), (64, 64, 3, 1, 24, 40, 2), (32, 64, 3, 2, 40, 40, 2),
+    (128, 256, 3, 2, 20, 20, 2), (64, 32, 1, 1, 40, 40, 2), (128, 128, 1, 1, 20, 20, 4), (256, 30, 1, 1, 20, 20, 2),
+    (40, 72, 3, 1, 10, 14, 2), (16, 32, 3, 2, 64, 64, 1), (512, 256, 1, 1, 4, 4, 3), (256, 128, 3, 1, 8, 8, 2)])
+def test_conv_wgrad_shapes(cin, cout, k, s, h, w, b):
+    """Weight gradient launch alone, every tile configuration, against float64 autograd; twice into the
+    same dw (accumulation) and bitwise repeatable."""
+    from objectdetection_amd._lib import lib, check
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    cpi, cpo = -(-cin // 8) * 8, -(-cout // 8) * 8
+    ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+    x = torch.randn(b, h, w, cpi, generator=g)
+    dy = torch.randn(b, ho, wo, cpo, generator=g)
+    xd = x[..., :cin].permute(0, 3, 1, 2).double()
+    dyd = dy[..., :cout].permute(0, 3, 1, 2).double()
+    wgt = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xd, wgt, stride=s, padding=k // 2).backward(dyd)
+    need = int(lib.odamd_conv_wgrad_workspace_bytes(b, h, w, cin, cout, k, s))
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+    xg, dyg = x.cuda(), dy.cuda()
+    outs = []
+    for rep in range(2):
+        dw = torch.zeros(cout, cin, k, k, device='cuda')
+        for _ in range(rep + 1):
+            check(lib.odamd_conv_wgrad(xg.data_ptr(), cpi, dyg.data_ptr(), cpo, dw.data_ptr(), b, h, w, cin, cout, k, s, 0,
+                                       ws.data_ptr(), need, None))
+        torch.cuda.synchronize()
+        outs.append(dw.cpu())
+    ref = wgt.grad
+    scale = float(ref.abs().max())
+    assert float((outs[0].double() - ref).abs().max()) <= 2e-5 * scale
+    assert float((outs[1].double() - 2 * ref).abs().max()) <= 4e-5 * scale
+    dw = torch.zeros(cout, cin, k, k, device='cuda')
+    check(lib.odamd_conv_wgrad(xg.data_ptr(), cpi, dyg.data_ptr(), cpo, dw.data_ptr(), b, h, w, cin, cout, k, s, 0,
+                               ws.data_ptr(), need, None))
+    assert torch.equal(dw.cpu(), outs[0])
+    assert lib.odamd_conv_wgrad(xg.data_ptr(), cpi, dyg.data_ptr(), cpo, dw.data_ptr(), b, h, w, cin, cout, k, s, 0,
+                                ws.data_ptr(), need - 4, None) == -3
