@@ -201,7 +201,15 @@ def main():
         else:
             ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
             roof = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
-        roof.update({'frac': roof['achieved'] / roof['peak'], 'traffic': None, 'kernel': dom_name,
+        # HBM bytes per launch of this kernel family from the committed rocprofv3 counter passes
+        # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); null when the file is absent
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')) as fh:
+                traffic = json.load(fh)['families'][dom_name]['traffic_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            pass
+        roof.update({'frac': roof['achieved'] / roof['peak'], 'traffic': traffic, 'kernel': dom_name,
                      'launches_per_step': dom['launches'], 'avg_launch_ms': dom['ms'] / dom['launches'],
                      'algorithmic_flops_per_step': dom['flops'], 'algorithmic_bytes_per_step': dom['bytes']})
         conv_flops = sum(f['flops'] for f in fam.values())
