@@ -11,12 +11,16 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = one 16
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-// float -> bf16 bits, round to nearest even (NaN kept a NaN by forcing a mantissa bit).
+// float -> bf16 bits, round to nearest even, NaN stays NaN: the plain cast is v_cvt_pk_bf16_f32.
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    const __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+// two floats -> packed bf16 pair (low half = a), one v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) __bf16 odamd_bf16x2_t;
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float a, float b) {
+    const odamd_bf16x2_t v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 

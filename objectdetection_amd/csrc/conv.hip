@@ -361,12 +361,13 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
 #undef ODAMD_COMMIT
 
 // ------------------------------------------------------------------------------------------
-// first layer: float32 NCHW image, 3 input channels, 3x3 stride 1 -> NHWC activations.
+// first layer, float32 compute: float32 NCHW image, 3 input channels, 3x3 stride 1 -> NHWC
+// activations as one fmaf chain per output in (ky, kx, c) order.
 // Weights are wave-uniform and come through scalar loads; one thread = one output pixel.
 // ------------------------------------------------------------------------------------------
 template <int DT>
 __global__ void __launch_bounds__(256)
-conv_first_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ scale,
+conv_first_valu_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ scale,
                   const float* __restrict__ shift, char* __restrict__ y, int H, int W, int Cout, int y_ld, int act) {
     constexpr int T = 16;
     __shared__ float patch[3][T + 2][T + 3];
@@ -417,6 +418,110 @@ conv_first_kernel(const float* __restrict__ img, const float* __restrict__ w, co
             for (int e = 0; c0 + e < Cout; ++e) {
                 if constexpr (DT == ODAMD_DTYPE_F32) ((float*)dst)[c0 + e] = o[e];
                 else ((uint16_t*)dst)[c0 + e] = f32_to_bf16(o[e]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// first layer: float32 NCHW image, 3 input channels, 3x3 stride 1 -> NHWC activations.
+// GEMM view D[co][pixel] with K = 27 (ky, kx, c) padded to 32 (bf16: one v_mfma_f32_16x16x32_bf16)
+// or 28 (f32: seven v_mfma_f32_16x16x4_f32, an exact fma chain in k order).  A workgroup stages the
+// f32 halo patch of a 16 x 64 pixel tile in LDS; a lane gathers its k values of one pixel through a
+// per-lane offset table (loop invariant), 16 consecutive pixels per MFMA; the weights sit in LDS as
+// [co][32] f32.  D gives a lane 4 consecutive channels of one pixel: the 64 lanes of a store cover
+// 16 pixels x 16 channels contiguously.
+// ------------------------------------------------------------------------------------------
+template <int DT>
+__global__ void __launch_bounds__(256)
+conv_first_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ scale,
+                  const float* __restrict__ shift, char* __restrict__ y, int H, int W, int Cout, int y_ld, int act) {
+    constexpr int TH = 16, TW = 64, PH = TH + 2, PW = TW + 3;        // odd row pitch
+    constexpr int ES = Elem<DT>::SIZE;
+    extern __shared__ __attribute__((aligned(16))) float fl[];
+    float* patch = fl;                          // [3][PH][PW]
+    float* wl = fl + 3 * PH * PW;               // [cout16][32]
+    const int b = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cpad = (Cout + 15) & ~15;
+    for (int i = tid; i < 3 * PH * (TW + 2); i += 256) {
+        const int c = i / (PH * (TW + 2)), rem = i - c * PH * (TW + 2);
+        const int iy = rem / (TW + 2), ix = rem - iy * (TW + 2);
+        const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+        patch[(c * PH + iy) * PW + ix] =
+            (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(((size_t)b * 3 + c) * H + gy) * W + gx] : 0.0f;
+    }
+    // reference weight layout (co, c, ky, kx) -> k = (ky*3 + kx)*3 + c, zero beyond 27 / Cout
+    for (int i = tid; i < cpad * 32; i += 256) {
+        const int co = i >> 5, k = i & 31;
+        float v = 0.0f;
+        if (co < Cout && k < 27) { const int c = k % 3, t = k / 3; v = w[(co * 3 + c) * 9 + t]; }
+        wl[i] = v;
+    }
+    __syncthreads();
+    const int j = lane & 15, kg = lane >> 4;
+    // patch offset of every k this lane feeds (padding k point at a valid word; their weight is zero)
+    constexpr int NK = DT == ODAMD_DTYPE_F32 ? 7 : 8;
+    int off[NK];
+#pragma unroll
+    for (int e = 0; e < NK; ++e) {
+        int k = DT == ODAMD_DTYPE_F32 ? 4 * e + kg : 8 * kg + e;
+        if (k > 26) k = 26;
+        const int c = k % 3, t = k / 3;
+        off[e] = (c * PH + t / 3) * PW + t % 3;
+    }
+    for (int cg = 0; cg < cpad; cg += 16) {
+        float wa[NK];
+#pragma unroll
+        for (int e = 0; e < NK; ++e) wa[e] = wl[(cg + j) * 32 + (DT == ODAMD_DTYPE_F32 ? 4 * e + kg : 8 * kg + e)];
+        float sc[4], sh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = min(cg + 4 * kg + e, Cout - 1);
+            sc[e] = scale ? scale[co] : 1.0f;
+            sh[e] = scale ? shift[co] : 0.0f;
+        }
+        bf16x8_t wb;
+        if constexpr (DT == ODAMD_DTYPE_BF16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wb[e] = (short)f32_to_bf16(wa[e]);
+        }
+        for (int g = wave; g < TH * (TW / 16); g += 4) {
+            const int ty = g / (TW / 16), tx = (g % (TW / 16)) * 16 + j;
+            const float* pp = patch + ty * PW + tx;
+            f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (DT == ODAMD_DTYPE_F32) {
+#pragma unroll
+                for (int e = 0; e < NK; ++e) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[e], pp[off[e]], d, 0, 0, 0);
+            } else {
+                bf16x8_t xb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xb[e] = (short)f32_to_bf16(pp[off[e]]);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb, d, 0, 0, 0);
+            }
+            const int oy = oy0 + ty, ox = ox0 + tx;
+            if (oy >= H || ox >= W) continue;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = scale ? d[e] * sc[e] + sh[e] : d[e];
+                o[e] = act ? silu<DT>(a) : a;
+            }
+            char* dst = y + ((((size_t)b * H + oy) * W + ox) * y_ld + cg + 4 * kg) * ES;
+            if (cg + 4 * kg + 4 <= Cout) {
+                if constexpr (DT == ODAMD_DTYPE_F32) {
+                    *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                    *(uint2*)dst = pk;
+                }
+            } else {
+                for (int e = 0; cg + 4 * kg + e < Cout; ++e) {
+                    if constexpr (DT == ODAMD_DTYPE_F32) ((float*)dst)[e] = o[e];
+                    else ((uint16_t*)dst)[e] = f32_to_bf16(o[e]);
+                }
             }
         }
     }
@@ -667,11 +772,14 @@ int odamd_conv_first_forward(const float* image, const float* w, const float* sc
     const int es = dtype == ODAMD_DTYPE_F32 ? 4 : 2;
     if (y_ld < cout) return ODAMD_E_SHAPE;
     if (((uintptr_t)y & 15) || (y_ld * es) % 16) return ODAMD_E_ALIGN;
-    dim3 grid((w_in + 15) / 16, (h + 15) / 16, batch);
-    if (dtype == ODAMD_DTYPE_F32)
-        conv_first_kernel<ODAMD_DTYPE_F32><<<grid, 256, 0, (hipStream_t)stream>>>(image, w, scale, shift, (char*)y, h, w_in, cout, y_ld, act);
+    if (cout > 1024) return ODAMD_E_SHAPE;
+    dim3 grid((w_in + 63) / 64, (h + 15) / 16, batch);
+    const size_t lds = ((size_t)3 * 18 * 67 + (size_t)((cout + 15) & ~15) * 32) * sizeof(float);
+    if (dtype == ODAMD_DTYPE_F32)   // float32 keeps the scalar fma chain (bit-stable against the float32 parity fixtures)
+        conv_first_valu_kernel<ODAMD_DTYPE_F32><<<dim3((w_in + 15) / 16, (h + 15) / 16, batch), 256, 0, (hipStream_t)stream>>>(
+            image, w, scale, shift, (char*)y, h, w_in, cout, y_ld, act);
     else
-        conv_first_kernel<ODAMD_DTYPE_BF16><<<grid, 256, 0, (hipStream_t)stream>>>(image, w, scale, shift, (char*)y, h, w_in, cout, y_ld, act);
+        conv_first_kernel<ODAMD_DTYPE_BF16><<<grid, 256, lds, (hipStream_t)stream>>>(image, w, scale, shift, (char*)y, h, w_in, cout, y_ld, act);
     return (int)hipGetLastError();
 }
 
