@@ -148,9 +148,11 @@ class yolov7(torch.nn.Module):
         heads.append(pb.head(self.head2, x))
         return heads
 
-    def _plan(self, x):
+    def _plan(self, x, slot=0):
+        """`slot` selects one of several independent plans (own buffers) of the same shape, so that a
+        consumer may still read the outputs of one forward while the next one runs."""
         dtype = engine.compute_dtype_for(self)
-        key = (tuple(x.shape), dtype, x.device.index)
+        key = (tuple(x.shape), dtype, x.device.index, slot)
         plan = self._plans.get(key)
         if plan is None:
             pb = engine.PlanBuilder(x.shape[0], dtype, x.device)
@@ -160,13 +162,13 @@ class yolov7(torch.nn.Module):
             self._plans[key] = plan
         return plan
 
-    def head_tensors(self, x):
+    def head_tensors(self, x, slot=0):
         """Run the network; returns the three raw head tensors (B, A, H, W, K) (views of plan memory)."""
         if not x.is_cuda:
             raise RuntimeError('objectdetection_amd runs on the GPU only (no CPU fallback)')
         if self.training:
             raise RuntimeError('training forward is not part of this build yet: call model.eval()')
-        plan = self._plan(x)
+        plan = self._plan(x, slot)
         plan.run(x.detach().float().contiguous())
         k = 5 + self.output_class
         out = []

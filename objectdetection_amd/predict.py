@@ -111,3 +111,50 @@ class predict_class:
     def _nms(self, pred):
         p = torch.as_tensor(np.ascontiguousarray(pred, dtype=np.float32)).cuda()
         return _post.nms_rows(p, self.iou_threshold).per_image()[0][0]
+
+
+class detect_pipeline:
+    """Batched detection as a two-stage pipeline on two HIP streams: the network of batch i+1 runs
+    while batch i is decoded, filtered, sorted and NMS-ed (predict.py:67-92 per image).  The network
+    is HBM-bound and the NMS mask VALU-bound, so the stages overlap well.  Two network plans
+    alternate, so the heads a post-processing pass reads are not overwritten by the next forward.
+
+        pipe = detect_pipeline(model, 0.5, 0.5)
+        results = [pipe.submit(batch) for batch in batches]     # asynchronous
+        pipe.synchronize()                                      # results' tensors are now final
+    """
+
+    def __init__(self, model, confidence_threshold, iou_threshold, anchor=None, input_size=None):
+        self.model = model
+        self.conf, self.iou = confidence_threshold, iou_threshold
+        self.anchor = anchor if anchor is not None else model.decode.anchor_rel
+        self.input_size = input_size if input_size is not None else model.decode.input_size
+        self.net_stream = torch.cuda.Stream()
+        self.post_stream = torch.cuda.Stream()
+        self.slot = 0
+        self.heads_free = [None, None]      # event: post-processing has finished reading the slot's heads
+
+    def submit(self, x, scale_xy=None):
+        """Enqueue one batch; returns its PostResult (device tensors, final once `result.done` has
+        completed or after `synchronize()`)."""
+        slot = self.slot
+        self.slot ^= 1
+        self.net_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.net_stream):
+            if self.heads_free[slot] is not None:
+                self.net_stream.wait_event(self.heads_free[slot])
+            heads = self.model.head_tensors(x, slot=slot)
+            ready = torch.cuda.Event()
+            ready.record(self.net_stream)
+        with torch.cuda.stream(self.post_stream):
+            self.post_stream.wait_event(ready)
+            res = _post.postprocess_heads(heads, self.input_size, self.anchor, self.conf, self.iou, scale_xy)
+            done = torch.cuda.Event()
+            done.record(self.post_stream)
+        self.heads_free[slot] = done
+        res.done = done
+        return res
+
+    def synchronize(self):
+        self.net_stream.synchronize()
+        self.post_stream.synchronize()
