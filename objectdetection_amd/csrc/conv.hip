@@ -68,6 +68,91 @@ __device__ __forceinline__ float silu(float v) {
     else return v * __frcp_rn(1.0f + __expf(-v));
 }
 
+// NHWC epilogue shared by the convolution kernels.  `acc[i][j]`: the wave's results for pixel
+// group i (32 pixels, lane r = pixel) and channel group j; `opix[i]`: output pixel index of (group i,
+// lane r) relative to `ybase`, -1 when outside; `stage`: wave-private LDS slice of 32 * (CGW*128 + 16) bytes.
+template <int DT, int PGW, int CGW>
+__device__ __forceinline__ void nhwc_epilogue(const f32x16_t (&acc)[PGW][CGW], const int (&opix)[PGW], char* stage, int lane,
+                                              int cw0, size_t ybase, const float* __restrict__ scale,
+                                              const float* __restrict__ shift, int Cout, char* __restrict__ y, int y_ld,
+                                              int act, int accum) {
+    constexpr int ES = Elem<DT>::SIZE;
+    const int r = lane & 31, h = lane >> 5;
+    // NHWC: the wave parks its raw f32 accumulators in a private LDS slice [32 pixels][32*CGW
+    // channels]; reading it back, every lane owns CPL fixed consecutive channels (so it fetches
+    // their scale/shift once), applies affine + SiLU and stores 16 bytes; LPR lanes cover one
+    // pixel's 64..256-byte channel run.
+    constexpr int CPL = 16 / ES;             // channels per lane in the read-back (16-byte store)
+    constexpr int NCH = CGW * 32;            // channels per pixel held by this wave
+    constexpr int RS = NCH * 4 + 16;         // padded LDS row (f32)
+    constexpr int LPR = NCH / CPL;           // lanes per pixel row
+    constexpr int RPP = 64 / LPR;            // pixel rows per pass
+        const int part = lane % LPR;
+    const int c_lane = cw0 + part * CPL;
+    float scl[CPL], shf[CPL];
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) {
+        scl[e] = (scale && c_lane + e < Cout) ? scale[c_lane + e] : 1.0f;
+        shf[e] = (shift && c_lane + e < Cout) ? shift[c_lane + e] : 0.0f;
+    }
+    #pragma unroll
+    for (int i = 0; i < PGW; ++i) {
+#pragma unroll
+        for (int j = 0; j < CGW; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(stage + r * RS + (j * 32 + 8 * g + 4 * h) * 4) =
+                    make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int row = ps * RPP + lane / LPR;
+            const int op = __shfl(opix[i], row);
+            float v[CPL];
+#pragma unroll
+            for (int e = 0; e < CPL; e += 4) {
+                const float4 t = *(const float4*)(stage + row * RS + (part * CPL + e) * 4);
+                v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+            }
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+                const float t = v[e] * scl[e] + shf[e];
+                v[e] = act ? silu<DT>(t) : t;
+            }
+            if (op >= 0 && c_lane < Cout) {
+                char* dst = y + ((ybase + op) * y_ld + c_lane) * ES;
+                if (accum) {
+                    if constexpr (DT == ODAMD_DTYPE_F32) {
+                        for (int e = 0; e < CPL; ++e)
+                            if (c_lane + e < Cout) v[e] += ((const float*)dst)[e];
+                    } else {
+                        for (int e = 0; e < CPL; ++e)
+                            if (c_lane + e < Cout) v[e] += bf16_to_f32(((const uint16_t*)dst)[e]);
+                    }
+                }
+                u32x4 pk;
+                if constexpr (DT == ODAMD_DTYPE_F32) {
+                    pk = u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                } else {
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    pk.z = (uint32_t)f32_to_bf16(v[4 % CPL]) | ((uint32_t)f32_to_bf16(v[5 % CPL]) << 16);
+                    pk.w = (uint32_t)f32_to_bf16(v[6 % CPL]) | ((uint32_t)f32_to_bf16(v[7 % CPL]) << 16);
+                }
+                if (c_lane + CPL <= Cout) {
+                    *(u32x4*)dst = pk;
+                } else {   // ragged channel tail
+                    for (int e = 0; c_lane + e < Cout; ++e) {
+                        if constexpr (DT == ODAMD_DTYPE_F32) ((float*)dst)[e] = v[e];
+                        else ((uint16_t*)dst)[e] = f32_to_bf16(v[e]);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 struct ConvP {
     const char* x; const char* w; const float* scale; const float* shift; char* y;
     int B, H, W, Ho, Wo, Cin, Cout, x_ld, y_ld;
@@ -281,84 +366,142 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
                 }
         return;
     }
-    // NHWC: the wave parks its raw f32 accumulators in a private LDS slice [32 pixels][32*CGW
-    // channels]; reading it back, every lane owns CPL fixed consecutive channels (so it fetches
-    // their scale/shift once), applies affine + SiLU and stores 16 bytes; LPR lanes cover one
-    // pixel's 64..256-byte channel run.
-    constexpr int CPL = 16 / ES;             // channels per lane in the read-back (16-byte store)
-    constexpr int NCH = CGW * 32;            // channels per pixel held by this wave
-    constexpr int RS = NCH * 4 + 16;         // padded LDS row (f32)
-    constexpr int LPR = NCH / CPL;           // lanes per pixel row
-    constexpr int RPP = 64 / LPR;            // pixel rows per pass
-    char* stage = lds + wave * (32 * RS);
-    const int part = lane % LPR;
-    const int c_lane = cw0 + part * CPL;
-    float scl[CPL], shf[CPL];
-#pragma unroll
-    for (int e = 0; e < CPL; ++e) {
-        scl[e] = (p.scale && c_lane + e < p.Cout) ? p.scale[c_lane + e] : 1.0f;
-        shf[e] = (p.shift && c_lane + e < p.Cout) ? p.shift[c_lane + e] : 0.0f;
-    }
-    const size_t ybase = (size_t)b * p.Ho * p.Wo;
-#pragma unroll
-    for (int i = 0; i < PGW; ++i) {
-#pragma unroll
-        for (int j = 0; j < CGW; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *(float4*)(stage + r * RS + (j * 32 + 8 * g + 4 * h) * 4) =
-                    make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int ps = 0; ps < 32 / RPP; ++ps) {
-            const int row = ps * RPP + lane / LPR;
-            const int op = __shfl(opix[i], row);
-            float v[CPL];
-#pragma unroll
-            for (int e = 0; e < CPL; e += 4) {
-                const float4 t = *(const float4*)(stage + row * RS + (part * CPL + e) * 4);
-                v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
-            }
-#pragma unroll
-            for (int e = 0; e < CPL; ++e) {
-                const float t = v[e] * scl[e] + shf[e];
-                v[e] = p.act ? silu<DT>(t) : t;
-            }
-            if (op >= 0 && c_lane < p.Cout) {
-                char* dst = p.y + ((ybase + op) * p.y_ld + c_lane) * ES;
-                if (p.accum) {
-                    if constexpr (DT == ODAMD_DTYPE_F32) {
-                        for (int e = 0; e < CPL; ++e)
-                            if (c_lane + e < p.Cout) v[e] += ((const float*)dst)[e];
-                    } else {
-                        for (int e = 0; e < CPL; ++e)
-                            if (c_lane + e < p.Cout) v[e] += bf16_to_f32(((const uint16_t*)dst)[e]);
-                    }
-                }
-                u32x4 pk;
-                if constexpr (DT == ODAMD_DTYPE_F32) {
-                    pk = u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                } else {
-                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    pk.z = (uint32_t)f32_to_bf16(v[4 % CPL]) | ((uint32_t)f32_to_bf16(v[5 % CPL]) << 16);
-                    pk.w = (uint32_t)f32_to_bf16(v[6 % CPL]) | ((uint32_t)f32_to_bf16(v[7 % CPL]) << 16);
-                }
-                if (c_lane + CPL <= p.Cout) {
-                    *(u32x4*)dst = pk;
-                } else {   // ragged channel tail
-                    for (int e = 0; c_lane + e < p.Cout; ++e) {
-                        if constexpr (DT == ODAMD_DTYPE_F32) ((float*)dst)[e] = v[e];
-                        else ((uint16_t*)dst)[e] = f32_to_bf16(v[e]);
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    // NHWC: transposed through a wave-private LDS slice (see nhwc_epilogue)
+    nhwc_epilogue<DT, PGW, CGW>(acc, opix, lds + wave * (32 * (CGW * 128 + 16)), lane, cw0, (size_t)b * p.Ho * p.Wo, p.scale,
+                                p.shift, p.Cout, p.y, p.y_ld, p.act, p.accum);
 }
 #undef ODAMD_FETCH
 #undef ODAMD_COMMIT
+
+// ------------------------------------------------------------------------------------------
+// Streaming 1x1 convolution (stride 1, NHWC in, NHWC out; the kernel handles up to 512 bytes of input
+// channels per pixel, the dispatcher uses it up to 256, where two workgroups fit a CU).  A 1x1 convolution has no spatial structure: the pixels of the whole batch form one flat
+// list.  A persistent workgroup keeps the weight slab of its 32*CG output channels in LDS for its
+// whole life and walks 128-pixel tiles tile, tile + gridDim.x, ...; the global loads of the next tile
+// are in registers while the matrix cores work on the current one, so HBM latency is hidden
+// inside the workgroup instead of relying on occupancy, and the weights are read once per
+// workgroup instead of once per tile.
+// ------------------------------------------------------------------------------------------
+struct StreamP {
+    const char* x; const char* w; const float* scale; const float* shift; char* y;
+    int npix, Cin, Cout, x_ld, y_ld, ntiles, act, accum, w_off;
+};
+
+template <int DT, int CG, int WP, int WC, int NPF>
+__global__ void __launch_bounds__(256) conv1x1_stream_kernel(StreamP p) {
+    constexpr int ES = Elem<DT>::SIZE;
+    constexpr int PG = 4, PGW = PG / WP, CGW = CG / WC;
+    static_assert(WP * WC == 4, "four waves");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int cbytes = p.Cin * ES;          // multiple of 32, <= 512
+    const int parts = cbytes >> 4;
+    const int RSB = cbytes + 16;            // LDS bytes per staged pixel / weight row
+    char* lds_in = lds;                     // [128][RSB], overlaid by the epilogue slices
+    char* lds_w = lds + p.w_off;            // [32*CG][RSB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wp = wave / WC, wc = wave % WC;
+    const int co0 = blockIdx.y * 32 * CG;
+
+    // weights: once
+    for (int i = tid; i < 32 * CG * parts; i += 256) {
+        const int row = i / parts, part = i - row * parts;
+        const int co = co0 + row;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (co < p.Cout) v = *(const u32x4*)(p.w + (size_t)co * cbytes + part * 16);
+        *(u32x4*)(lds_w + row * RSB + part * 16) = v;
+    }
+    int a_off[CGW], b_off[PGW];
+#pragma unroll
+    for (int j = 0; j < CGW; ++j) a_off[j] = ((wc * CGW + j) * 32 + r) * RSB + 16 * h;
+#pragma unroll
+    for (int i = 0; i < PGW; ++i) b_off[i] = ((wp * PGW + i) * 32 + r) * RSB + 16 * h;
+    // staged piece j of this thread: pixel (tid + 256 j) / parts of the tile, 16-byte part % parts
+    int g_off[NPF], l_off[NPF], g_pix[NPF];
+    const int n_in = 128 * parts;
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+        const int i = tid + j * 256;
+        const int pix = i / parts, part = i - pix * parts;
+        g_pix[j] = i < n_in ? pix : (1 << 30);
+        g_off[j] = pix * p.x_ld * ES + part * 16;
+        l_off[j] = pix * RSB + part * 16;
+    }
+    const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
+    u32x4 v_in[NPF];
+    const size_t tile_bytes = (size_t)128 * p.x_ld * ES;
+#define ODAMD_SFETCH(T)                                                                          \
+    {                                                                                            \
+        const char* xb_ = p.x + (size_t)(T) * tile_bytes;                                        \
+        const int left_ = p.npix - (T) * 128;                                                    \
+        _Pragma("unroll") for (int j = 0; j < NPF; ++j)                                          \
+            v_in[j] = g_pix[j] < left_ ? *(const u32x4*)(xb_ + g_off[j]) : zero;                 \
+    }
+    int t = blockIdx.x;
+    if (t < p.ntiles) ODAMD_SFETCH(t)
+    for (; t < p.ntiles; t += gridDim.x) {
+        __syncthreads();                     // epilogue slices (overlaying lds_in) of the previous tile are done
+#pragma unroll
+        for (int j = 0; j < NPF; ++j)
+            if (g_pix[j] < 128) *(u32x4*)(lds_in + l_off[j]) = v_in[j];
+        __syncthreads();
+        if (t + (int)gridDim.x < p.ntiles) ODAMD_SFETCH(t + gridDim.x)   // in flight during the matrix work
+        f32x16_t acc[PGW][CGW];
+#pragma unroll
+        for (int i = 0; i < PGW; ++i)
+#pragma unroll
+            for (int j = 0; j < CGW; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        for (int c0 = 0; c0 < cbytes; c0 += 128) {
+            // float32: chunk sums first, then the running sum (same rounding structure as conv_igemm_kernel)
+            f32x16_t part[DT == ODAMD_DTYPE_F32 ? PGW : 1][DT == ODAMD_DTYPE_F32 ? CGW : 1];
+            if constexpr (DT == ODAMD_DTYPE_F32) {
+#pragma unroll
+                for (int i = 0; i < PGW; ++i)
+#pragma unroll
+                    for (int j = 0; j < CGW; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) part[i][j][e] = 0.0f;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (c0 + s * 32 < cbytes) {
+                    u32x4 a[CGW], bb[PGW];
+#pragma unroll
+                    for (int j = 0; j < CGW; ++j) a[j] = *(const u32x4*)(lds_w + a_off[j] + c0 + s * 32);
+#pragma unroll
+                    for (int i = 0; i < PGW; ++i) bb[i] = *(const u32x4*)(lds_in + b_off[i] + c0 + s * 32);
+#pragma unroll
+                    for (int i = 0; i < PGW; ++i)
+#pragma unroll
+                        for (int j = 0; j < CGW; ++j) {
+                            if constexpr (DT == ODAMD_DTYPE_F32) mma_step<DT>(part[i][j], a[j], bb[i]);
+                            else mma_step<DT>(acc[i][j], a[j], bb[i]);
+                        }
+                }
+            }
+            if constexpr (DT == ODAMD_DTYPE_F32) {
+#pragma unroll
+                for (int i = 0; i < PGW; ++i)
+#pragma unroll
+                    for (int j = 0; j < CGW; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] += part[i][j][e];
+            }
+        }
+        __syncthreads();                     // every wave has finished reading lds_in
+        int opix[PGW];
+#pragma unroll
+        for (int i = 0; i < PGW; ++i) {
+            const int q = t * 128 + (wp * PGW + i) * 32 + r;
+            opix[i] = q < p.npix ? q : -1;
+        }
+        nhwc_epilogue<DT, PGW, CGW>(acc, opix, lds + wave * (32 * (CGW * 128 + 16)), lane, co0 + wc * CGW * 32, 0, p.scale,
+                                    p.shift, p.Cout, p.y, p.y_ld, p.act, p.accum);
+    }
+#undef ODAMD_SFETCH
+}
 
 // ------------------------------------------------------------------------------------------
 // first layer, float32 compute: float32 NCHW image, 3 input channels, 3x3 stride 1 -> NHWC
@@ -697,9 +840,48 @@ int dispatch_cg(const ConvP& p, hipStream_t st) {
     return launch_conv<DT, KS, ST, 4, 4, 2, 2, CKB, POOL>(p, st);
 }
 
+template <int DT, int CG, int WP, int WC>
+int launch_stream(const ConvP& c, hipStream_t st) {
+    constexpr int ES = Elem<DT>::SIZE;
+    StreamP p = {};
+    p.x = c.x; p.w = c.w; p.scale = c.scale; p.shift = c.shift; p.y = c.y;
+    p.npix = c.B * c.H * c.W; p.Cin = c.Cin; p.Cout = c.Cout; p.x_ld = c.x_ld; p.y_ld = c.y_ld;
+    p.ntiles = (p.npix + 127) / 128; p.act = c.act; p.accum = c.accum;
+    const int cbytes = c.Cin * ES, rsb = cbytes + 16;
+    const size_t epi = (size_t)4 * 32 * ((CG / WC) * 128 + 16);
+    size_t in_bytes = (size_t)128 * rsb;
+    if (in_bytes < epi) in_bytes = epi;
+    p.w_off = (int)((in_bytes + 255) & ~(size_t)255);
+    const size_t lds = p.w_off + (size_t)32 * CG * rsb;
+    const int ncb = (c.Cout + 32 * CG - 1) / (32 * CG);
+    int gx = (lds <= 80 * 1024 ? 512 : 256) / ncb;
+    gx = (gx + 7) & ~7;                       // channel blocks of one tile land on the same XCD
+    if (gx > p.ntiles) gx = p.ntiles;
+    const dim3 grid(gx, ncb);
+    const int parts = cbytes / 16;
+#define ODAMD_STREAM(NPF)                                                                                        \
+    {                                                                                                            \
+        auto k = conv1x1_stream_kernel<DT, CG, WP, WC, NPF>;                                                     \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        k<<<grid, 256, lds, st>>>(p);                                                                            \
+    }
+    if (parts <= 8) ODAMD_STREAM(4)
+    else if (parts <= 16) ODAMD_STREAM(8)
+    else return ODAMD_E_SHAPE;
+#undef ODAMD_STREAM
+    return (int)hipGetLastError();
+}
+
 template <int DT>
 int dispatch_conv(const ConvP& p, int ks, int stride, hipStream_t st) {
     const int cin_bytes = p.Cin * Elem<DT>::SIZE;
+    // large plain 1x1 layers: persistent streaming kernel
+    if (ks == 1 && stride == 1 && !p.pool && !p.upz && !p.nchw && cin_bytes <= 256 &&
+        (long long)p.B * p.H * p.W >= 256 * 128 && (long long)p.B * p.H * p.W < (1ll << 30) / (p.x_ld * Elem<DT>::SIZE) * 128) {
+        if (p.Cout <= 32) return launch_stream<DT, 1, 4, 1>(p, st);
+        if (p.Cout <= 64) return launch_stream<DT, 2, 2, 2>(p, st);
+        return launch_stream<DT, 4, 2, 2>(p, st);
+    }
     if (ks == 1 && stride == 1) {
         if (p.pool) {
             if (cin_bytes % 64 == 0) return dispatch_cg<DT, 1, 1, 64, true>(p, st);

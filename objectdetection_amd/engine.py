@@ -183,7 +183,32 @@ class Plan:
         self.weight_version = None
         self.outputs = {}
         self.finish = finish
+        self._fuse_sibling_convs()
         self._build()
+
+    def _fuse_sibling_convs(self):
+        """Two consecutive 1x1 stride-1 cbs blocks that read the same activation and write adjacent
+        channel ranges of one buffer (cbs0/cbs1 of elan and elan_h) become ONE launch with the
+        weights stacked: the input is read from HBM once instead of twice."""
+        ops, out, i = self.b.ops, [], 0
+        while i < len(ops):
+            a = ops[i]
+            b = ops[i + 1] if i + 1 < len(ops) else None
+            if (b is not None and a['kind'] == 'conv' and b['kind'] == 'conv' and a['x'] is b['x']
+                    and a['k'] == 1 and b['k'] == 1 and a['s'] == 1 and b['s'] == 1 and not a['pool'] and not b['pool']
+                    and a['y'].buf == b['y'].buf and a['y'].c == a['y'].cphys and len(b['y'].segments) == 1
+                    and b['y'].c0 == a['y'].c0 + a['y'].cphys):
+                ya, yb = a['y'], b['y']
+                f = dict(a)
+                f['mods'] = [a['mod'], b['mod']]
+                f['y'] = Act(ya.buf, ya.c0, [(0, ya.c + yb.c)], ya.h, ya.w, ya.align)
+                out.append(f)
+                i += 2
+            else:
+                out.append(a)
+                i += 1
+        self.b.ops = out
+        self.b.convs = [op for op in out if op['kind'] in ('conv', 'head', 'first')]
 
     # ---- addressing ----------------------------------------------------------------------
     def _ptr(self, act):
@@ -197,12 +222,12 @@ class Plan:
     def _versions(self):
         v = 0
         for op in self.b.convs:
-            m = op['mod']
-            if op['kind'] == 'head':
-                v += m.output.weight._version + m.output.bias._version
-            else:
-                v += m.conv.weight._version + m.bn.weight._version + m.bn.bias._version
-                v += m.bn.running_mean._version + m.bn.running_var._version
+            for m in op.get('mods', [op['mod']]):
+                if op['kind'] == 'head':
+                    v += m.output.weight._version + m.output.bias._version
+                else:
+                    v += m.conv.weight._version + m.bn.weight._version + m.bn.bias._version
+                    v += m.bn.running_mean._version + m.bn.running_var._version
         return v
 
     def refresh_weights(self):
@@ -223,11 +248,11 @@ class Plan:
                     op['scale'].copy_(sc)
                     op['shift'].copy_(sh)
                 else:
-                    w = _pack_weight(m.conv.weight, op['x'], self.b.dtype)
-                    op['w'].copy_(w.view(-1))
-                    sc, sh = _fold_bn(m.bn)
-                    op['scale'].copy_(sc)
-                    op['shift'].copy_(sh)
+                    mods = op.get('mods', [m])
+                    op['w'].copy_(torch.cat([_pack_weight(q.conv.weight, op['x'], self.b.dtype).view(-1) for q in mods]))
+                    folded = [_fold_bn(q.bn) for q in mods]
+                    op['scale'].copy_(torch.cat([f[0] for f in folded]))
+                    op['shift'].copy_(torch.cat([f[1] for f in folded]))
         self.weight_version = ver
 
     # ---- lowering ---------------------------------------------------------------------------
@@ -239,7 +264,7 @@ class Plan:
             if kind in ('conv', 'head'):
                 m, x = op['mod'], op['x']
                 conv = m.output if kind == 'head' else m.conv
-                cout, k = conv.out_channels, op['k']
+                cout, k = sum(q.conv.out_channels for q in op['mods']) if 'mods' in op else conv.out_channels, op['k']
                 op['w'] = torch.empty(cout * k * k * x.cphys, dtype=dt, device=dev)
                 op['shift'] = torch.empty(cout, dtype=torch.float32, device=dev)
                 op['scale'] = None if kind == 'head' else torch.empty(cout, dtype=torch.float32, device=dev)

@@ -40,6 +40,12 @@ BLOCK_CASES = [
     ('cbs', dict(in_=64, out_=160, kernel_size=3, stride=2), (1, 64, 20, 20)),
     ('cbs', dict(in_=128, out_=64, kernel_size=1, stride=1), (2, 128, 33, 17)),
     ('cbs', dict(in_=48, out_=80, kernel_size=3, stride=1), (1, 48, 20, 20)),
+    # >= 32768 pixels: the persistent streaming 1x1 kernel (ragged last tile, 1..2 channel blocks, partial chunk)
+    ('cbs', dict(in_=64, out_=32, kernel_size=1, stride=1), (2, 64, 128, 128)),
+    ('cbs', dict(in_=128, out_=128, kernel_size=1, stride=1), (2, 128, 128, 130)),
+    ('cbs', dict(in_=256, out_=256, kernel_size=1, stride=1), (1, 256, 192, 192)),
+    ('cbs', dict(in_=32, out_=64, kernel_size=1, stride=1), (3, 32, 120, 120)),
+    ('cbs', dict(in_=96, out_=40, kernel_size=1, stride=1), (1, 96, 200, 170)),
     ('elan', dict(in_=16, out_=32, n=1), (2, 16, 12, 12)),
     ('elan', dict(in_=32, out_=64, n=2), (1, 32, 16, 16)),
     ('elan_h', dict(in_=64, out_=32), (2, 64, 8, 8)),
