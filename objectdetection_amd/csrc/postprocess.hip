@@ -137,14 +137,24 @@ filter_kernel(FilterSrc fs, DecodeGeom g, int rows, int kdim, int rows_stage, fl
     if (nrow <= 0) return;
     const int row0 = fs.row_first[s] + lrow0;
     const int ldk = kdim | 1;
-    {   // coalesced copy, (row, column) advanced incrementally: no division per element
+    {   // coalesced copy into the padded rows; 16-byte loads when the range start is aligned
         const float* src = fs.base[s] + ((size_t)b * fs.rows_in[s] + lrow0) * kdim;
-        int r = threadIdx.x / kdim, k = threadIdx.x - r * kdim;
-        const int dr = FILTER_THREADS / kdim, dk = FILTER_THREADS - dr * kdim;
-        for (int f = threadIdx.x; f < nrow * kdim; f += FILTER_THREADS) {
-            lds[r * ldk + k] = src[f];
-            r += dr; k += dk;
-            if (k >= kdim) { k -= kdim; ++r; }
+        const int total = nrow * kdim;
+        const int nvec = (((uintptr_t)src & 15) == 0) ? total >> 2 : 0;
+        for (int v = threadIdx.x; v < nvec; v += FILTER_THREADS) {
+            const float4 t = ((const float4*)src)[v];
+            const int f = v << 2;
+            int r = f / kdim, k = f - r * kdim;
+            const float e[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lds[r * ldk + k] = e[i];
+                if (++k == kdim) { k = 0; ++r; }
+            }
+        }
+        for (int f = (nvec << 2) + threadIdx.x; f < total; f += FILTER_THREADS) {
+            const int r = f / kdim;
+            lds[r * ldk + (f - r * kdim)] = src[f];
         }
     }
     __syncthreads();
@@ -171,8 +181,11 @@ filter_kernel(FilterSrc fs, DecodeGeom g, int rows, int kdim, int rows_stage, fl
                 const float ymin = SRC == 2 ? cy : cy - bh / 2.0f;
                 pass = SRC == 2 || ((xmin > 0.0f) && (ymin > 0.0f));
                 if (pass) {
-                    float m = SRC == 1 ? sigmoid_f32(p[5]) : p[5];
-                    for (int k = 6; k < kdim; ++k) m = fmaxf(m, SRC == 1 ? sigmoid_f32(p[k]) : p[k]);
+                    // the sigmoid is monotone, so the largest class probability is the sigmoid of the
+                    // largest class logit: one exp per surviving row instead of one per class
+                    float m = p[5];
+                    for (int k = 6; k < kdim; ++k) m = fmaxf(m, p[k]);
+                    if (SRC == 1) m = sigmoid_f32(m);
                     key = make_key(conf * m, row0 + r);
                     rowbox[(size_t)b * rows + row0 + r] = make_float4(xmin, ymin, bw, bh);
                 }
@@ -624,10 +637,11 @@ int postprocess_impl(const float* pred, const DecodeGeom& g, int batch, int rows
     if ((rc = (int)hipMemsetAsync(w.removed, 0, (size_t)batch * (n_pad / 64) * 8, st))) return rc;
     if ((rc = (int)hipMemsetAsync(w.count, 0, (size_t)batch * 4, st))) return rc;
     if ((rc = (int)hipMemsetAsync(out_count, 0, (size_t)batch * 4, st))) return rc;
-    // rows staged per workgroup: as many as fit 48 KiB, at most one per thread
+    // rows staged per workgroup: one wave's worth (about 22 KiB at 85 columns, so seven workgroups
+    // per CU keep enough loads in flight), fewer when rows are very wide
     const int ldk = kdim | 1;
     int rows_stage = (48 * 1024) / (ldk * 4);
-    if (rows_stage > FILTER_THREADS) rows_stage = FILTER_THREADS;
+    if (rows_stage > 64) rows_stage = 64;
     if (rows_stage < 1) return ODAMD_E_ARG;  // more than ~12k classes
     FilterSrc fs = {};
     int nstage = 0;
