@@ -161,6 +161,7 @@ struct ConvP {
     int act, pool, nchw;
     int upz;    // input is zero-upsampled x2 on load (data gradient of a stride-2 convolution)
     int accum;  // NHWC epilogue adds to the destination instead of overwriting it
+    int upskip; // upz with even tiles: pixel groups are parity classes and skip the taps that only meet zeros
     int nblocks;
 };
 
@@ -221,6 +222,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
     for (int i = 0; i < PGW; ++i) {
         const int q = (wp * PGW + i) * 32 + r;
         int ty = q / p.TW, tx = q - ty * p.TW;
+        if (KS == 3 && ST == 1 && p.upskip) {
+            // zero-upsampled input: group g holds pixels of one (row parity, column parity) class
+            // g & 3, so that whole MFMA groups can skip the taps that land on inserted zeros
+            const int g = wp * PGW + i, hw = p.TW >> 1;
+            const int m = (g >> 2) * 32 + r;
+            const int my = m / hw, mx = m - my * hw;
+            ty = 2 * my + ((g >> 1) & 1);
+            tx = 2 * mx + (g & 1);
+        }
         const int oy = oy0 + ty, ox = ox0 + tx;
         opix[i] = (ty < p.TH && oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
         if (ty >= p.TH) { ty = 0; tx = 0; }
@@ -325,12 +335,18 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
 #pragma unroll
                 for (int i = 0; i < PGW; ++i) bb[i] = *(const u32x4*)(lds_in + b_off[i] + tap_off + s * 32);
 #pragma unroll
-                for (int i = 0; i < PGW; ++i)
+                for (int i = 0; i < PGW; ++i) {
+                    if (KS == 3 && ST == 1 && p.upskip) {
+                        // tap (ky, kx) meets data only where (row + ky) and (column + kx) are odd
+                        const int g = wp * PGW + i;
+                        if (!((((g >> 1) + tap / KS) & 1) && ((g + tap % KS) & 1))) continue;
+                    }
 #pragma unroll
                     for (int j = 0; j < CGW; ++j) {
                         if constexpr (DT == ODAMD_DTYPE_F32) mma_step<DT>(part[i][j], a[j], bb[i]);
                         else mma_step<DT>(acc[i][j], a[j], bb[i]);
                     }
+                }
             }
         }
         if constexpr (DT == ODAMD_DTYPE_F32) {
@@ -795,7 +811,7 @@ struct TileChoice { int th, tw, ih, iw; bool ok; };
 
 // Pick the output patch (TH x TW <= npix pixels) that stages the fewest input pixels overall
 // and whose halo patch + weight slab fit in LDS.
-TileChoice choose_tile(int Ho, int Wo, int npix, int ks, int st, int ps, size_t w_bytes, int max_pix) {
+TileChoice choose_tile(int Ho, int Wo, int npix, int ks, int st, int ps, size_t w_bytes, int max_pix, bool even = false) {
     const int cand[] = {Wo, 64, 40, 32, 20, 16, 8};
     TileChoice best = {0, 0, 0, 0, false};
     double best_cost = 1e30;
@@ -803,6 +819,7 @@ TileChoice choose_tile(int Ho, int Wo, int npix, int ks, int st, int ps, size_t 
         if (tw > Wo || tw > npix || tw < 1) continue;
         int th = npix / tw;
         if (th > Ho) th = Ho;
+        if (even) { if ((tw & 1) || th < 2) continue; th &= ~1; }
         if (th < 1) continue;
         const int ih = (th - 1) * st + ks, iw = (tw - 1) * st + ks;
         if (ih * iw > max_pix) continue;
@@ -819,7 +836,13 @@ int launch_conv(ConvP p, hipStream_t st) {
     constexpr int ES = Elem<DT>::SIZE;
     constexpr int PS = CKB + 16, WRS = KS * KS * CKB + 16;
     const size_t w_bytes = (size_t)32 * CG * WRS;
-    TileChoice t = choose_tile(p.Ho, p.Wo, 32 * PG, KS, ST, PS, w_bytes, max_in_pix(KS, ST, PG));
+    TileChoice t = {0, 0, 0, 0, false};
+    p.upskip = 0;
+    if (KS == 3 && ST == 1 && p.upz && PG % 4 == 0) {   // even tiles make the parity-class tap skipping possible
+        t = choose_tile(p.Ho, p.Wo, 32 * PG, KS, ST, PS, w_bytes, max_in_pix(KS, ST, PG), true);
+        p.upskip = t.ok;
+    }
+    if (!t.ok) t = choose_tile(p.Ho, p.Wo, 32 * PG, KS, ST, PS, w_bytes, max_in_pix(KS, ST, PG));
     if (!t.ok) return ODAMD_E_SHAPE;
     p.TH = t.th; p.TW = t.tw; p.IH = t.ih; p.IW = t.iw;
     p.tiles_x = (p.Wo + t.tw - 1) / t.tw;
