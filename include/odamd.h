@@ -199,12 +199,12 @@ int odamd_bn_silu_backward(void* y_dy, int y_ld, const void* dact, int dact_ld, 
 int odamd_bias_grad(const void* dy, int dy_ld, size_t npix, int channels, float* dbias, int dtype, void* workspace,
                     size_t workspace_bytes, void* stream);
 
-/* Backward of MaxPool2d(2,2), of a stride-1 MaxPool2d(k, pad k/2) (float32 only) and of nearest
+/* Backward of MaxPool2d(2,2), of a stride-1 MaxPool2d(k, pad k/2) (bf16: planes of <= 1024 pixels) and of nearest
  * Upsample x2.  All ADD into dx.  Ties go to the first maximum in row-major window order. */
 int odamd_maxpool2_backward(const void* x, int x_ld, const void* dy, int dy_ld, void* dx, int dx_ld, int batch, int h,
                             int w, int c, int dtype, void* stream);
-int odamd_maxpool_s1_backward(const float* x, int x_ld, const float* dy, int dy_ld, float* dx, int dx_ld, int batch,
-                              int h, int w, int c, int ksize, void* stream);
+int odamd_maxpool_s1_backward(const void* x, int x_ld, const void* dy, int dy_ld, void* dx, int dx_ld, int batch,
+                              int h, int w, int c, int ksize, int dtype, void* stream);
 int odamd_upsample2_backward(const void* dy, int dy_ld, void* dx, int dx_ld, int batch, int h, int w, int c,
                              int dtype, void* stream);
 
@@ -212,8 +212,9 @@ int odamd_upsample2_backward(const void* dy, int dy_ld, void* dx, int dx_ld, int
  * in the reference's parameter layout, ADDED to.  x: (B,H,W) NHWC input, dy: NHWC gradient of the
  * raw output.  Workgroups store partial sums to `workspace` (odamd_conv_wgrad_workspace_bytes of the
  * same shape) and a second launch folds them into dw in a fixed order: no atomics, the result is
- * reproducible run to run.  dtype float32 only in this version. */
-size_t odamd_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int ksize, int stride);
+ * reproducible run to run.  dtype: element type of x and dy (float32 on v_mfma_f32_32x32x2_f32, bf16 on
+ * v_mfma_f32_32x32x16_bf16); dw and the accumulation are float32 in both. */
+size_t odamd_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int ksize, int stride, int dtype);
 int odamd_conv_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int batch, int h, int w, int cin,
                      int cout, int ksize, int stride, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -610,12 +610,10 @@ conv_first_kernel(const float* __restrict__ img, const float* __restrict__ w, co
         patch[(c * PH + iy) * PW + ix] =
             (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(((size_t)b * 3 + c) * H + gy) * W + gx] : 0.0f;
     }
-    // reference weight layout (co, c, ky, kx) -> k = (ky*3 + kx)*3 + c, zero beyond 27 / Cout
+    // weights [co][ky][kx][c]: k = (ky*3 + kx)*3 + c is their own order; zero beyond 27 / Cout
     for (int i = tid; i < cpad * 32; i += 256) {
         const int co = i >> 5, k = i & 31;
-        float v = 0.0f;
-        if (co < Cout && k < 27) { const int c = k % 3, t = k / 3; v = w[(co * 3 + c) * 9 + t]; }
-        wl[i] = v;
+        wl[i] = (co < Cout && k < 27) ? w[co * 27 + k] : 0.0f;
     }
     __syncthreads();
     const int j = lane & 15, kg = lane >> 4;

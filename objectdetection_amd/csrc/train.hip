@@ -301,6 +301,46 @@ maxpool_s1_bwd_kernel(const float* __restrict__ x, int x_ld, const float* __rest
     }
 }
 
+// bf16 variant: one workgroup per (image, 8-channel vector).  The input plane and a float32
+// gradient plane live in LDS; windows scatter with LDS float adds, then the plane is added to dx.
+__global__ void __launch_bounds__(256)
+maxpool_s1_bwd_bf16_kernel(const char* __restrict__ x, int x_ld, const char* __restrict__ dy, int dy_ld,
+                           char* __restrict__ dx, int dx_ld, int H, int W, int k) {
+    extern __shared__ __attribute__((aligned(16))) float pl[];
+    const int hw = H * W, v = blockIdx.x, b = blockIdx.y, rad = k / 2;
+    float* grad = pl;                  // [hw][8]
+    float* val = pl + (size_t)hw * 8;  // [hw][8]
+    for (int p = threadIdx.x; p < hw; p += 256) {
+        float t[8];
+        Vec<ODAMD_DTYPE_BF16>::load(x + (((size_t)b * hw + p) * x_ld) * 2 + v * 16, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { val[p * 8 + e] = t[e]; grad[p * 8 + e] = 0.0f; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < hw * 8; i += 256) {
+        const int e = i & 7, p = i >> 3;
+        const int oy = p / W, ox = p - oy * W;
+        float m = -INFINITY;
+        int arg = 0;
+        for (int gy = max(oy - rad, 0); gy <= min(oy + rad, H - 1); ++gy)
+            for (int gx = max(ox - rad, 0); gx <= min(ox + rad, W - 1); ++gx) {
+                const float t = val[(gy * W + gx) * 8 + e];
+                if (t > m) { m = t; arg = gy * W + gx; }
+            }
+        const uint16_t g = *(const uint16_t*)(dy + (((size_t)b * hw + p) * dy_ld) * 2 + v * 16 + e * 2);
+        atomicAdd(&grad[arg * 8 + e], bf16_to_f32(g));
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < hw; p += 256) {
+        float t[8];
+        char* d = dx + (((size_t)b * hw + p) * dx_ld) * 2 + v * 16;
+        Vec<ODAMD_DTYPE_BF16>::load(d, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] += grad[p * 8 + e];
+        Vec<ODAMD_DTYPE_BF16>::store(d, t);
+    }
+}
+
 // nearest x2 upsample: dx(y, x) += sum of the 2x2 block of dy.
 template <int DT>
 __global__ void __launch_bounds__(256)
@@ -341,7 +381,7 @@ upsample2_bwd_kernel(const char* __restrict__ dy, int dy_ld, char* __restrict__ 
 // same patches) run on the same XCD and share its L2.
 // ------------------------------------------------------------------------------------------
 struct WgradP {
-    const float* x; const float* dy; float* part;
+    const void* x; const void* dy; float* part;
     int B, H, W, Ho, Wo, Cin, Cout, x_ld, dy_ld;
     int TH, TW, npix, tiles_x, tiles_y, IH, IW, nsplit, ntiles, ncin, npairs;
     size_t slice;
@@ -394,7 +434,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_f32_kernel(WgradP p) {
             const int oy = oy0 + ty, ox = ox0 + tx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ty < p.TH && oy < p.Ho && ox < p.Wo && part * 4 < nco) {
-                const float* s = p.dy + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0 + part * 4;
+                const float* s = (const float*)p.dy + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0 + part * 4;
                 if (part * 4 + 4 <= nco) v = *(const float4*)s;
                 else { v.x = s[0]; if (part * 4 + 1 < nco) v.y = s[1]; if (part * 4 + 2 < nco) v.z = s[2]; }
             }
@@ -407,7 +447,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_f32_kernel(WgradP p) {
             const int gy = iy0 + hy, gx = ix0 + pix - hy * p.IW;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && part * 4 < nci) {
-                const float* s = p.x + (((size_t)b * p.H + gy) * p.W + gx) * p.x_ld + ci0 + part * 4;
+                const float* s = (const float*)p.x + (((size_t)b * p.H + gy) * p.W + gx) * p.x_ld + ci0 + part * 4;
                 if (part * 4 + 4 <= nci) v = *(const float4*)s;
                 else { v.x = s[0]; if (part * 4 + 1 < nci) v.y = s[1]; if (part * 4 + 2 < nci) v.z = s[2]; }
             }
@@ -434,6 +474,129 @@ __global__ void __launch_bounds__(256) conv_wgrad_f32_kernel(WgradP p) {
         }
     }
     // D[row = co][col = ci]: lane holds col = lane&31, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
+    float* out = p.part + ((size_t)split * WPX + wpx) * p.slice;    // one slice per pixel group
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int rc = 0; rc < R; ++rc) {
+            const int ci = ci0 + (wci * R + rc) * 32 + col;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + (wco * R + r) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                if (co < p.Cout && ci < p.Cin) {
+                    float* o = out + ((size_t)co * p.Cin + ci) * TAPS;
+#pragma unroll
+                    for (int tp = 0; tp < TAPS; ++tp) o[tp] = acc[(tp * R + r) * R + rc][e];
+                }
+            }
+        }
+}
+
+// Same GEMM on v_mfma_f32_32x32x16_bf16 for bf16 activations / gradients (float32 accumulation and
+// float32 dW).  The MFMA wants, per lane, 8 consecutive K (= pixel) values of one channel, while the
+// staged NHWC patches keep channels contiguous: a lane gathers its 8 pixels with eight 16-bit LDS
+// reads (32 consecutive channels per half wave: conflict free), so no transposed copy and no
+// alignment constraint on the tap shifts.  One K step covers 16 pixels of the patch.
+__device__ __forceinline__ uint4 mask_bf16x8(uint4 v, int valid) {   // keep the first `valid` (1..7) elements
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (e >= valid) w[e >> 1] &= (e & 1) ? 0x0000FFFFu : 0xFFFF0000u;
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int KS, int ST, int WCO, int WCI, int R>
+__global__ void __launch_bounds__(256) conv_wgrad_bf16_kernel(WgradP p) {
+    constexpr int TAPS = KS * KS, PAD = (KS - 1) / 2;
+    constexpr int CO_T = 32 * WCO * R, CI_T = 32 * WCI * R, WPX = 4 / (WCO * WCI);
+    constexpr int NACC = TAPS * R * R;
+    constexpr int PCO = CO_T / 8, PCI = CI_T / 8;          // 16-byte pieces per staged pixel
+    extern __shared__ __attribute__((aligned(16))) char wl8[];
+    const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+    const int pair = slot % p.npairs, split = (slot / p.npairs) * 8 + xcd;
+    if (split >= p.nsplit) return;
+    const int npix = p.npix, nhalo = p.IH * p.IW;
+    int* tab = (int*)wl8;                                   // [npix] halo element offset of tap (0,0)
+    uint16_t* dyl = (uint16_t*)(wl8 + (size_t)npix * 4);    // [npix][CO_T]
+    uint16_t* xl = dyl + (size_t)npix * CO_T;               // [IH*IW][CI_T]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, kk = lane >> 5;
+    const int wco = wave % WCO, wci = (wave / WCO) % WCI, wpx = wave / (WCO * WCI);
+    const int cb = pair / p.ncin, ib = pair % p.ncin;
+    const int co0 = cb * CO_T, ci0 = ib * CI_T;
+    const int nco = min(CO_T, p.Cout - co0), nci = min(CI_T, p.Cin - ci0);
+    const uint16_t* xg = (const uint16_t*)p.x;
+    const uint16_t* dyg = (const uint16_t*)p.dy;
+
+    for (int q = tid; q < npix; q += 256) {
+        const int ty = q / p.TW, tx = q - ty * p.TW;
+        tab[q] = ty < p.TH ? ((ty * ST) * p.IW + tx * ST) * CI_T : 0;
+    }
+    int tapoff[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) tapoff[t] = ((t / KS) * p.IW + (t % KS)) * CI_T;
+
+    f32x16_t acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][e] = 0.0f;
+
+    const int steps = npix >> 4;
+    const int s0 = wpx * (steps / WPX), s1 = s0 + steps / WPX;
+    for (int t = split; t < p.ntiles; t += p.nsplit) {
+        const int b = t / (p.tiles_x * p.tiles_y), tt = t % (p.tiles_x * p.tiles_y);
+        const int oy0 = (tt / p.tiles_x) * p.TH, ox0 = (tt % p.tiles_x) * p.TW;
+        __syncthreads();
+        for (int i = tid; i < npix * PCO; i += 256) {
+            const int pix = i / PCO, part = i % PCO;
+            const int ty = pix / p.TW, tx = pix - ty * p.TW;
+            const int oy = oy0 + ty, ox = ox0 + tx;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (ty < p.TH && oy < p.Ho && ox < p.Wo && part * 8 < nco) {
+                v = *(const uint4*)(dyg + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0 + part * 8);
+                if (part * 8 + 8 > nco) v = mask_bf16x8(v, nco - part * 8);
+            }
+            *(uint4*)(dyl + pix * CO_T + part * 8) = v;
+        }
+        const int iy0 = oy0 * ST - PAD, ix0 = ox0 * ST - PAD;
+        for (int i = tid; i < nhalo * PCI; i += 256) {
+            const int pix = i / PCI, part = i % PCI;
+            const int hy = pix / p.IW;
+            const int gy = iy0 + hy, gx = ix0 + pix - hy * p.IW;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && part * 8 < nci) {
+                v = *(const uint4*)(xg + (((size_t)b * p.H + gy) * p.W + gx) * p.x_ld + ci0 + part * 8);
+                if (part * 8 + 8 > nci) v = mask_bf16x8(v, nci - part * 8);
+            }
+            *(uint4*)(xl + pix * CI_T + part * 8) = v;
+        }
+        __syncthreads();
+        for (int s = s0; s < s1; ++s) {
+            const int q0 = 16 * s + 8 * kk;
+            const int4 t0 = *(const int4*)(tab + q0), t1 = *(const int4*)(tab + q0 + 4);
+            const int xo[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            const uint16_t* ap = dyl + q0 * CO_T + wco * R * 32 + col;
+            const uint16_t* bp = xl + wci * R * 32 + col;
+            bf16x8_t a[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[r][e] = (short)ap[e * CO_T + r * 32];
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                for (int rc = 0; rc < R; ++rc) {
+                    bf16x8_t bv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bv[e] = (short)bp[xo[e] + tapoff[tp] + rc * 32];
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        acc[(tp * R + r) * R + rc] =
+                            __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r], bv, acc[(tp * R + r) * R + rc], 0, 0, 0);
+                }
+        }
+    }
     float* out = p.part + ((size_t)split * WPX + wpx) * p.slice;    // one slice per pixel group
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -715,7 +878,7 @@ struct WgradPlan {
 };
 
 // Tile shape, patch shape and split count of one weight-gradient launch.
-int wgrad_plan(int batch, int h, int w, int cin, int cout, int ksize, int stride, WgradPlan& o) {
+int wgrad_plan(int batch, int h, int w, int cin, int cout, int ksize, int stride, int dtype, WgradPlan& o) {
     if (batch < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return ODAMD_E_ARG;
     if (!((ksize == 1 && stride == 1) || (ksize == 3 && (stride == 1 || stride == 2)))) return ODAMD_E_ARG;
     WgradP& p = o.p;
@@ -733,19 +896,17 @@ int wgrad_plan(int batch, int h, int w, int cin, int cout, int ksize, int stride
     for (int d = p.Wo < 40 ? p.Wo : 40; d >= 8; --d)
         if (p.Wo % d == 0) { p.TW = d; break; }
     if (p.TW == 0) p.TW = p.Wo < 32 ? p.Wo : 32;
-    // patch height: as many rows as keep the staging under 64 KB (two workgroups per CU), at most 128 pixels
-    for (p.TH = (128 / p.TW > 1 ? 128 / p.TW : 1);; --p.TH) {
-        p.npix = (p.TH * p.TW + 7) & ~7;
+    // patch height: as many rows as keep the staging under 64 KB (two workgroups per CU), at most 128
+    // pixels (float32) or 256 (bf16); the pixel count is padded to whole K steps for every pixel group
+    const int es = dtype == ODAMD_DTYPE_F32 ? 4 : 2;
+    const int round = dtype == ODAMD_DTYPE_F32 ? 8 : 64, maxpix = dtype == ODAMD_DTYPE_F32 ? 128 : 256;
+    for (p.TH = (maxpix / p.TW > 1 ? maxpix / p.TW : 1);; --p.TH) {
+        if (p.TH > p.Ho) continue;
+        p.npix = (p.TH * p.TW + round - 1) / round * round;
         p.IH = (p.TH - 1) * stride + ksize;
         p.IW = (p.TW - 1) * stride + ksize;
-        o.lds = ((size_t)p.npix * co_t + (size_t)p.IH * p.IW * ci_t) * sizeof(float) + (size_t)p.npix * sizeof(int);
+        o.lds = ((size_t)p.npix * co_t + (size_t)p.IH * p.IW * ci_t) * es + (size_t)p.npix * sizeof(int);
         if (o.lds <= 64 * 1024 || p.TH == 1) break;
-    }
-    if (p.TH > p.Ho) {
-        p.TH = p.Ho;
-        p.npix = (p.TH * p.TW + 7) & ~7;
-        p.IH = (p.TH - 1) * stride + ksize;
-        o.lds = ((size_t)p.npix * co_t + (size_t)p.IH * p.IW * ci_t) * sizeof(float) + (size_t)p.npix * sizeof(int);
     }
     if (o.lds > 160 * 1024) return ODAMD_E_SHAPE;
     p.tiles_x = (p.Wo + p.TW - 1) / p.TW;
@@ -763,12 +924,12 @@ int wgrad_plan(int batch, int h, int w, int cin, int cout, int ksize, int stride
     return ODAMD_OK;
 }
 
-template <int KS, int ST>
+template <int DT, int KS, int ST>
 void wgrad_launch(const WgradPlan& o, hipStream_t st) {
     const int key = o.wco * 100 + o.wci * 10 + o.r;
 #define ODAMD_WG(WCO, WCI, R)                                                                                     \
     case WCO * 100 + WCI * 10 + R: {                                                                              \
-        auto k = conv_wgrad_f32_kernel<KS, ST, WCO, WCI, R>;                                                      \
+        auto k = DT == ODAMD_DTYPE_F32 ? conv_wgrad_f32_kernel<KS, ST, WCO, WCI, R> : conv_wgrad_bf16_kernel<KS, ST, WCO, WCI, R>; \
         if (o.lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o.lds); \
         k<<<o.grid, 256, o.lds, st>>>(o.p);                                                                       \
         break;                                                                                                    \
@@ -882,10 +1043,22 @@ int odamd_maxpool2_backward(const void* x, int x_ld, const void* dy, int dy_ld, 
     return (int)hipGetLastError();
 }
 
-int odamd_maxpool_s1_backward(const float* x, int x_ld, const float* dy, int dy_ld, float* dx, int dx_ld, int batch, int h,
-                              int w, int c, int ksize, void* stream) {
+int odamd_maxpool_s1_backward(const void* x, int x_ld, const void* dy, int dy_ld, void* dx, int dx_ld, int batch, int h,
+                              int w, int c, int ksize, int dtype, void* stream) {
     if (!x || !dy || !dx || batch < 1 || h < 1 || w < 1 || c < 1 || ksize < 1 || !(ksize & 1)) return ODAMD_E_ARG;
-    maxpool_s1_bwd_kernel<<<ew_grid((size_t)batch * h * w * c), 256, 0, (hipStream_t)stream>>>(x, x_ld, dy, dy_ld, dx, dx_ld, batch, h, w, c, ksize);
+    if (dtype == ODAMD_DTYPE_F32) {
+        maxpool_s1_bwd_kernel<<<ew_grid((size_t)batch * h * w * c), 256, 0, (hipStream_t)stream>>>(
+            (const float*)x, x_ld, (const float*)dy, dy_ld, (float*)dx, dx_ld, batch, h, w, c, ksize);
+    } else if (dtype == ODAMD_DTYPE_BF16) {
+        if ((c & 7) || (x_ld & 7) || (dy_ld & 7) || (dx_ld & 7) || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15))
+            return ODAMD_E_ALIGN;
+        const size_t lds = (size_t)h * w * 16 * sizeof(float);
+        if (lds > 64 * 1024) return ODAMD_E_SHAPE;     // planes of up to 1024 pixels (the 20x20 .. 32x32 SPP maps)
+        maxpool_s1_bwd_bf16_kernel<<<dim3(c / 8, batch), 256, lds, (hipStream_t)stream>>>(
+            (const char*)x, x_ld, (const char*)dy, dy_ld, (char*)dx, dx_ld, h, w, ksize);
+    } else {
+        return ODAMD_E_ARG;
+    }
     return (int)hipGetLastError();
 }
 
@@ -904,27 +1077,35 @@ int odamd_upsample2_backward(const void* dy, int dy_ld, void* dx, int dx_ld, int
     return (int)hipGetLastError();
 }
 
-size_t odamd_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int ksize, int stride) {
+size_t odamd_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int ksize, int stride, int dtype) {
     WgradPlan o;
-    if (wgrad_plan(batch, h, w, cin, cout, ksize, stride, o) != ODAMD_OK) return 0;
+    if (dtype != ODAMD_DTYPE_F32 && dtype != ODAMD_DTYPE_BF16) return 0;
+    if (wgrad_plan(batch, h, w, cin, cout, ksize, stride, dtype, o) != ODAMD_OK) return 0;
     return (size_t)o.nslices * o.p.slice * sizeof(float);
 }
 
 int odamd_conv_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int batch, int h, int w, int cin,
                      int cout, int ksize, int stride, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !dy || !dw || !workspace) return ODAMD_E_ARG;
-    if (dtype != ODAMD_DTYPE_F32) return ODAMD_E_ARG;   // bf16 activations: not built yet
-    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)workspace & 15) || (x_ld & 3) || (dy_ld & 3)) return ODAMD_E_ALIGN;
+    if (dtype != ODAMD_DTYPE_F32 && dtype != ODAMD_DTYPE_BF16) return ODAMD_E_ARG;
+    const int per = dtype == ODAMD_DTYPE_F32 ? 4 : 8;    // elements per 16-byte piece
+    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)workspace & 15) || (x_ld % per) || (dy_ld % per)) return ODAMD_E_ALIGN;
     WgradPlan o;
-    const int rc = wgrad_plan(batch, h, w, cin, cout, ksize, stride, o);
+    const int rc = wgrad_plan(batch, h, w, cin, cout, ksize, stride, dtype, o);
     if (rc != ODAMD_OK) return rc;
     if (workspace_bytes < (size_t)o.nslices * o.p.slice * sizeof(float)) return ODAMD_E_WORKSPACE;
-    o.p.x = (const float*)x; o.p.dy = (const float*)dy; o.p.part = (float*)workspace;
+    o.p.x = x; o.p.dy = dy; o.p.part = (float*)workspace;
     o.p.x_ld = x_ld; o.p.dy_ld = dy_ld;
     hipStream_t st = (hipStream_t)stream;
-    if (ksize == 1) wgrad_launch<1, 1>(o, st);
-    else if (stride == 1) wgrad_launch<3, 1>(o, st);
-    else wgrad_launch<3, 2>(o, st);
+    if (dtype == ODAMD_DTYPE_F32) {
+        if (ksize == 1) wgrad_launch<ODAMD_DTYPE_F32, 1, 1>(o, st);
+        else if (stride == 1) wgrad_launch<ODAMD_DTYPE_F32, 3, 1>(o, st);
+        else wgrad_launch<ODAMD_DTYPE_F32, 3, 2>(o, st);
+    } else {
+        if (ksize == 1) wgrad_launch<ODAMD_DTYPE_BF16, 1, 1>(o, st);
+        else if (stride == 1) wgrad_launch<ODAMD_DTYPE_BF16, 3, 1>(o, st);
+        else wgrad_launch<ODAMD_DTYPE_BF16, 3, 2>(o, st);
+    }
     int err = (int)hipGetLastError();
     if (err) return err;
     wgrad_fold_kernel<<<(unsigned)((o.p.slice + 31) / 32), 256, 0, st>>>(o.p.part, o.p.slice, o.nslices, dw);

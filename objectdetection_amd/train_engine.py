@@ -384,7 +384,7 @@ class TrainPlan:
         need = 16
         for fn, args, name, _ in bwd:
             if name == 'wgrad':
-                need = max(need, int(lib.odamd_conv_wgrad_workspace_bytes(*args[5:12])))
+                need = max(need, int(lib.odamd_conv_wgrad_workspace_bytes(*args[5:13])))
         self.wgrad_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
         for fn, args, name, _ in bwd:
             if name == 'wgrad':

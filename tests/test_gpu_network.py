@@ -140,3 +140,77 @@ def test_network_640_bf16_vs_f32_oracle(od):
         assert got.shape == (2, 25200, 85)
         assert rel_err(got[..., :4], ref[..., :4]) < TOL[dtype], (dtype, rel_err(got[..., :4], ref[..., :4]))
         assert rel_err(got[..., 4:], ref[..., 4:]) < TOL[dtype], (dtype, rel_err(got[..., 4:], ref[..., 4:]))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('cout,h,w', [(16, 64, 64), (24, 37, 70), (40, 16, 130)])
+def test_first_layer_entry_point(cout, h, w, dtype):
+    """odamd_conv_first_forward alone (weights [cout][ky][kx][3]) against torch conv2d on random data."""
+    from objectdetection_amd._lib import lib, check
+    g = torch.Generator().manual_seed(cout + h)
+    x = torch.rand(2, 3, h, w, generator=g)
+    wt = torch.randn(cout, 3, 3, 3, generator=g) * 0.3
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.2
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), padding=1) * scale.double()[None, :, None, None] \
+        + shift.double()[None, :, None, None]
+    ref = torch.nn.functional.silu(ref).permute(0, 2, 3, 1)
+    dt = 0 if dtype == 'f32' else 1
+    ld = -(-cout // 16) * 16
+    y = torch.zeros(2, h, w, ld, dtype=torch.float32 if dt == 0 else torch.bfloat16, device='cuda')
+    xg, wg = x.cuda(), wt.permute(0, 2, 3, 1).contiguous().cuda()
+    sg, hg = scale.cuda(), shift.cuda()
+    check(lib.odamd_conv_first_forward(xg.data_ptr(), wg.data_ptr(), sg.data_ptr(), hg.data_ptr(), y.data_ptr(), 2, h, w,
+                                       cout, ld, 1, dt, None))
+    torch.cuda.synchronize()
+    got = y[..., :cout].float().cpu().double()
+    assert rel_err(got.numpy(), ref.numpy()) < (1e-5 if dt == 0 else 1.5e-2)
+    assert float(y[..., cout:].float().abs().max()) == 0.0 if ld > cout else True
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_every_layer_against_oracle_taps(od, dtype):
+    """Every cbs output inside the whole network (random weights and BN statistics, 128x128 input)
+    against the oracle's activation of the same name: a wrong layer cannot hide behind the heads."""
+    engine, layer, ymod = od
+    args = patterns.default_args(input_size=128, output_class=4)
+    torch.manual_seed(11)
+    net = ymod.yolov7(args)
+    g = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.bias.shape, generator=g) * 0.5 + 0.25)
+    x = torch.rand(2, 3, 128, 128, generator=g)
+    taps = {}
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        network.yolov7_forward(sd, x, args, taps=taps)
+    net = net.cuda().eval()
+    names = {m: n for n, m in net.named_modules()}
+    engine.set_compute_dtype(dtype)
+    try:
+        xg = x.cuda()
+        net(xg)
+        plan = net._plan(xg)
+    finally:
+        engine.set_compute_dtype(None)
+    checked, worst = 0, 0.0
+    for op in plan.b.ops:
+        if op['kind'] not in ('conv', 'first'):
+            continue
+        y = op['y']
+        buf = plan.bufs[y.buf][..., y.c0:y.c0 + y.cphys].float().cpu()
+        c0 = 0
+        for m in op.get('mods', [op['mod']]):
+            ref = taps[names[m]].permute(0, 2, 3, 1)
+            got = buf[..., c0:c0 + ref.shape[3]]
+            c0 += ref.shape[3]
+            err = rel_err(got.numpy(), ref.numpy())
+            worst = max(worst, err)
+            assert err < TOL[dtype], (names[m], err)
+            checked += 1
+    assert checked >= 55, checked

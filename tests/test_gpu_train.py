@@ -210,7 +210,7 @@ def test_conv_wgrad_shapes(cin, cout, k, s, h, w, b):
     dyd = dy[..., :cout].permute(0, 3, 1, 2).double()
     wgt = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
     torch.nn.functional.conv2d(xd, wgt, stride=s, padding=k // 2).backward(dyd)
-    need = int(lib.odamd_conv_wgrad_workspace_bytes(b, h, w, cin, cout, k, s))
+    need = int(lib.odamd_conv_wgrad_workspace_bytes(b, h, w, cin, cout, k, s, 0))
     assert need > 0
     ws = torch.empty(need, dtype=torch.uint8, device='cuda')
     xg, dyg = x.cuda(), dy.cuda()
