@@ -68,16 +68,16 @@ def cpu_baseline(model, a, margs, x_cpu):
             'forward_ms_per_image': t_fwd * 1e3, 'postprocess_s_per_image': t_post}
 
 
-def train_leg(a, dev, rank, world, dist, steps, warmup):
+def train_leg(a, dev, rank, world, dist, steps, warmup, amp=False):
     """Training step (configs[2]/[3]): forward (batch-statistics BN) + loss + backward + bucketed
-    gradient all-reduce (RCCL when world > 1) + fused Adam/EMA, float32, `--train-batch` synthetic
+    gradient all-reduce (RCCL when world > 1) + fused Adam/EMA, float32 or (amp) bf16 mixed precision, `--train-batch` synthetic
     images per GPU with 8 synthetic boxes each.  Weak scaling: global batch = world * train-batch."""
     from objectdetection_amd.train_class import train_class, synthetic_dataset
     from oracle import patterns
     targs = patterns.default_args(input_size=a.size, output_class=a.train_classes)
     targs.__dict__.update(device=f'cuda:{dev.index}', batch=a.train_batch, epoch=1, lr_start=0.001, lr_end_ratio=0.1,
                           lr_end_epoch=100, warmup_ratio=0.01, regularization='L2', r_value=0.0005, ema=True,
-                          distributed=world > 1, local_rank=rank, weight_path='', weight_again=True,
+                          distributed=world > 1, local_rank=rank, weight_path='', weight_again=True, amp=amp,
                           print_info=False, save_path=None)
     torch.manual_seed(999)
     ds = synthetic_dataset(targs, a.train_batch * world, seed=999)
@@ -112,7 +112,8 @@ def train_leg(a, dev, rank, world, dist, steps, warmup):
         dt = float(t.item())
     last = l.tolist()
     return {'images_per_sec': world * a.train_batch * steps / dt, 'ms_per_step': dt / steps * 1e3,
-            'global_batch': world * a.train_batch, 'dtype': 'f32', 'classes': a.train_classes, 'steps': steps,
+            'global_batch': world * a.train_batch, 'dtype': 'bf16 (f32 accumulate / statistics / master weights)' if amp else 'f32',
+            'classes': a.train_classes, 'steps': steps,
             'parallelism': f'dp{world}' + (' (RCCL all-reduce, 3 buckets behind backward)' if world > 1 else ''),
             'positives_per_step': int(sum(len(s) for s in screen)),
             'loss_first': first, 'loss_last': last, 'params': tc.model.train_state().n}, tc
@@ -252,10 +253,15 @@ def main():
         guard.start()
         del model, x
         tsteps = a.train_steps if a.train_steps is not None else a.steps
-        train, _ = train_leg(a, dev, rank, world, dist, tsteps, max(a.warmup, 2))
+        train, tc_ = train_leg(a, dev, rank, world, dist, tsteps, max(a.warmup, 2))
+        del tc_
+        torch.cuda.empty_cache()
+        train_amp, tc_ = train_leg(a, dev, rank, world, dist, tsteps, max(a.warmup, 2), amp=True)
+        del tc_
         guard.cancel()
         if rank == 0:
-            out['train'] = train
+            out['train'] = train                 # float32: the reference default (--amp False)
+            out['train_amp'] = train_amp         # bf16 mixed precision: the --amp True mode
             if a.workload == 'train':
                 infer = {k: out[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'dtype', 'config')}
                 out.update({'metric': 'images/sec @640^2 training step (fwd + loss + bwd + all-reduce + Adam/EMA)',

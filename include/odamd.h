@@ -239,8 +239,9 @@ int odamd_ema_update(float* ema, const float* src, size_t n, double decay, void*
 /* Packs master float32 weights into the kernels' layouts for every convolution at once.
  * table_dev: device array of n_entries descriptors of odamd_pack_desc_bytes() bytes each:
  *   { const float* w; void* fwd; void* bwd; int cout, cin, k, cin_phys, cout_phys, n_seg;
- *     int seg_off[8], seg_len[8]; }
- * fwd: [cout][ky][kx][cin_phys]; bwd: [cin_phys][2-ky][2-kx][cout_phys] (data-gradient weights). */
+ *     int seg_off[8], seg_len[8]; int fwd_f32, reserved; }
+ * fwd: [cout][ky][kx][cin_phys]; bwd: [cin_phys][2-ky][2-kx][cout_phys] (data-gradient weights), both in
+ * `dtype`; fwd_f32 = 1 keeps the forward copy float32 (odamd_conv_first_forward takes float32 weights). */
 int odamd_pack_weights(const void* table_dev, int n_entries, int dtype, void* stream);
 size_t odamd_pack_desc_bytes(void);
 

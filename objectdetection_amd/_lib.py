@@ -43,7 +43,7 @@ class PackDesc(C.Structure):
     """One entry of the odamd_pack_weights table."""
     _fields_ = [('w', c_void_p), ('fwd', c_void_p), ('bwd', c_void_p), ('cout', c_int), ('cin', c_int), ('k', c_int),
                 ('cin_phys', c_int), ('cout_phys', c_int), ('n_seg', c_int), ('seg_off', c_int * 8),
-                ('seg_len', c_int * 8)]
+                ('seg_len', c_int * 8), ('fwd_f32', c_int), ('reserved', c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/odamd.h declares must appear here.
@@ -79,7 +79,7 @@ SIGNATURES = {
     'odamd_maxpool2_backward': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_void_p]),
     'odamd_maxpool_s1_backward': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                          c_int, c_void_p]),
+                                          c_int, c_int, c_void_p]),
     'odamd_upsample2_backward': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'odamd_conv_wgrad_workspace_bytes': (c_size_t, [c_int] * 8),
     'odamd_conv_wgrad': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -819,6 +819,8 @@ struct PackDesc {
     int cout, cin, k, cin_phys, cout_phys;
     int n_seg;            // cin is spread over segments of the consumer's input buffer
     int seg_off[8], seg_len[8];
+    int fwd_f32;          // 1: the forward copy stays float32 whatever the dtype (first-layer kernel)
+    int reserved;
 };
 
 __global__ void __launch_bounds__(256) pack_weights_kernel(const PackDesc* __restrict__ table, int dtype) {
@@ -837,7 +839,7 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const PackDesc* __res
         }
         if (d.fwd) {
             const size_t o = ((size_t)co * kk + t) * d.cin_phys + phys;
-            if (dtype == ODAMD_DTYPE_F32) ((float*)d.fwd)[o] = v; else ((uint16_t*)d.fwd)[o] = f32_to_bf16(v);
+            if (dtype == ODAMD_DTYPE_F32 || d.fwd_f32) ((float*)d.fwd)[o] = v; else ((uint16_t*)d.fwd)[o] = f32_to_bf16(v);
         }
         if (d.bwd) {
             const size_t o = ((size_t)phys * kk + (kk - 1 - t)) * d.cout_phys + co;

@@ -197,11 +197,15 @@ class yolov7(torch.nn.Module):
         return self._state
 
     def train_plan(self, batch, size):
+        """Training plan in `self.train_dtype`: 'f32' (the reference default) or 'bf16' (the mixed
+        precision mode that `--amp True` selects: bf16 activations / gradients / MFMA operands,
+        float32 accumulation, statistics, master weights and optimizer)."""
         from .. import train_engine
-        key = (batch, size)
+        dtype = engine.BF16 if getattr(self, 'train_dtype', 'f32') == 'bf16' else engine.F32
+        key = (batch, size, dtype)
         plan = self._train_plans.get(key)
         if plan is None:
-            plan = self._train_plans[key] = train_engine.TrainPlan(self, self.train_state(), batch, size)
+            plan = self._train_plans[key] = train_engine.TrainPlan(self, self.train_state(), batch, size, dtype)
         return plan
 
     def forward_train(self, x):

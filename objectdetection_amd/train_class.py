@@ -228,6 +228,8 @@ class train_class:
         self.model_dict = self.model_load()
         self.model_dict['model'] = self.model_dict['model'].to(args.device)
         self.model = self.model_dict['model']
+        # --amp (train_class.py:29, fp16 autocast in the reference) selects the bf16 mixed-precision step
+        self.model.train_dtype = 'bf16' if getattr(args, 'amp', False) else 'f32'
         self.train_dataloader = dataloader if dataloader is not None else self.dataloader_load()
         self.optimizer, self.optimizer_adjust = self.optimizer_load()
         self.loss = loss_class(args)

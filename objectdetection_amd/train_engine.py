@@ -135,8 +135,6 @@ class TrainPlan:
     def __init__(self, model, state, batch, size, dtype=F32, block_input=None):
         """`model`: a yolov7 mirror (whole network incl. decode), or any block when `block_input`
         = (channels, height, width) is given (NCHW float32 in, NCHW float32 out; used by tests)."""
-        if dtype != F32:
-            raise NotImplementedError('the training step computes in float32 in this version')
         self.model, self.state, self.batch, self.size, self.dtype = model, state, batch, size, dtype
         dev = state.param.device
         self.dev = dev
@@ -153,7 +151,8 @@ class TrainPlan:
         else:
             self.head_ops = model._emit(pb, (size, size))
         self.pb = pb
-        self.es = 4
+        self.es = 4 if dtype == F32 else 2
+        self.tdt = torch.float32 if dtype == F32 else torch.bfloat16     # activations, gradients, packed weights
         self._lower()
 
     # ---- helpers ---------------------------------------------------------------------------
@@ -179,14 +178,14 @@ class TrainPlan:
             ops.append(op)
         self.ops = ops
         # activation buffers and their gradients (one pool, zeroed once per step)
-        self.bufs = [torch.zeros((B, h, w, c), dtype=torch.float32, device=dev) for c, h, w in pb.buffers]
+        self.bufs = [torch.zeros((B, h, w, c), dtype=self.tdt, device=dev) for c, h, w in pb.buffers]
         total = sum(t.numel() for t in self.bufs)
-        self.grad_pool = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad_pool = torch.zeros(total, dtype=self.tdt, device=dev)
         self.gbufs, o = [], 0
         for t in self.bufs:
             self.gbufs.append(self.grad_pool[o:o + t.numel()].view(t.shape))
             o += t.numel()
-        self.image8 = None if self.block else torch.zeros((B, self.size, self.size, 8), dtype=torch.float32, device=dev)
+        self.image8 = None if self.block else torch.zeros((B, self.size, self.size, 8), dtype=self.tdt, device=dev)
         maxc = 16
         self.fwd, self.bwd = [], []
         self.keep = []
@@ -200,7 +199,7 @@ class TrainPlan:
                 cphys = _round_up(cout, self.pb.align)
                 y_act = op['y']
                 ho, wo = y_act.h, y_act.w
-                raw = torch.zeros((B, ho, wo, cphys), dtype=torch.float32, device=dev)
+                raw = torch.zeros((B, ho, wo, cphys), dtype=self.tdt, device=dev)
                 stats = torch.zeros((4, cout), dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
                 op['raw'], op['stats'] = raw, stats
                 maxc = max(maxc, cphys)
@@ -208,7 +207,9 @@ class TrainPlan:
                 k = m.conv.kernel_size[0]
                 if kind == 'first':
                     wf = torch.empty(cout * 27, dtype=torch.float32, device=dev)
-                    pack.append(self._pack_desc(m.conv.weight, wf, None, None, cout))
+                    pd = self._pack_desc(m.conv.weight, wf, None, None, cout)
+                    pd.fwd_f32 = 1          # the first-layer kernel takes float32 weights in both modes
+                    pack.append(pd)
                     op['wf'] = wf
                     self.fwd.append((lib.odamd_conv_first_forward,
                                      [None, wf.data_ptr(), None, None, raw.data_ptr(), B, ho, wo, cout, cphys, 0,
@@ -216,8 +217,8 @@ class TrainPlan:
                 else:
                     x = op['x']
                     assert x.cphys == x.c, 'training needs gap-free channel slices (widths that are multiples of 16)'
-                    wf = torch.empty(cout * k * k * x.cphys, dtype=torch.float32, device=dev)
-                    wb = torch.zeros(x.cphys * k * k * cphys, dtype=torch.float32, device=dev)
+                    wf = torch.empty(cout * k * k * x.cphys, dtype=self.tdt, device=dev)
+                    wb = torch.zeros(x.cphys * k * k * cphys, dtype=self.tdt, device=dev)
                     pack.append(self._pack_desc(m.conv.weight, wf, wb, x, cout))
                     op['wf'], op['wb'] = wf, wb
                     d = self._conv_desc(self._aptr(x), wf, None, raw.data_ptr(), x.h, x.w, x.cphys, cout, self._ld(x),
@@ -228,11 +229,11 @@ class TrainPlan:
                 m, x = op['mod'], op['x']
                 cout = m.output.out_channels
                 cphys = _round_up(cout, self.pb.align)
-                wf = torch.empty(cout * x.cphys, dtype=torch.float32, device=dev)
-                wb = torch.zeros(x.cphys * cphys, dtype=torch.float32, device=dev)
+                wf = torch.empty(cout * x.cphys, dtype=self.tdt, device=dev)
+                wb = torch.zeros(x.cphys * cphys, dtype=self.tdt, device=dev)
                 pack.append(self._pack_desc(m.output.weight, wf, wb, x, cout))
                 out = torch.empty((B, cout, x.h, x.w), dtype=torch.float32, device=dev)
-                dyb = torch.zeros((B, x.h, x.w, cphys), dtype=torch.float32, device=dev)
+                dyb = torch.zeros((B, x.h, x.w, cphys), dtype=self.tdt, device=dev)
                 op.update(wf=wf, wb=wb, out=out, dy=dyb)
                 maxc = max(maxc, cphys)
                 d = self._conv_desc(self._aptr(x), wf, m.output.bias, out.data_ptr(), x.h, x.w, x.cphys, cout,
@@ -261,7 +262,7 @@ class TrainPlan:
                 x, dst = op['x'], 0
                 for off, n in x.segments:
                     self.fwd.append((lib.odamd_nhwc_to_nchw,
-                                     [self._aptr(x) + off * 4, self.out_nchw.data_ptr() + dst * x.h * x.w * 4, B, n, x.h,
+                                     [self._aptr(x) + off * self.es, self.out_nchw.data_ptr() + dst * x.h * x.w * 4, B, n, x.h,
                                       x.w, self._ld(x), x.c, self.dtype], 'to_nchw', None))
                     dst += n
             else:
@@ -362,7 +363,7 @@ class TrainPlan:
                 for y, kk in zip(ys, (5, 9, 13)):
                     bwd.append((lib.odamd_maxpool_s1_backward,
                                 [self._aptr(x), self._ld(x), self._gptr(y), self._ld(y), self._gptr(x), self._ld(x), B,
-                                 x.h, x.w, x.cphys, kk], 'spp_bwd', None))
+                                 x.h, x.w, x.cphys, kk, self.dtype], 'spp_bwd', None))
             elif kind == 'from_nchw':
                 y = op['y']
                 bwd.append((lib.odamd_nhwc_to_nchw,
@@ -372,7 +373,7 @@ class TrainPlan:
                 x, dst = op['x'], 0
                 for off, n in x.segments:
                     bwd.append((lib.odamd_nchw_to_nhwc,
-                                [self.gout_nchw.data_ptr() + dst * x.h * x.w * 4, self._gptr(x) + off * 4, B, n, x.h, x.w,
+                                [self.gout_nchw.data_ptr() + dst * x.h * x.w * 4, self._gptr(x) + off * self.es, B, n, x.h, x.w,
                                  x.c, self._ld(x), self.dtype], 'gout_to_nhwc', None))
                     dst += n
             elif kind == 'upsample2':
