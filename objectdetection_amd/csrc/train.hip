@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int RED_MAX_BLOCKS = 512;
+constexpr int RED_MAX_BLOCKS = 1024;
 
 __device__ __forceinline__ float silu_f(float z) { return z / (1.0f + expf(-z)); }
 // d silu / dz = s (1 + z (1 - s)),  s = sigmoid(z)
@@ -82,24 +82,37 @@ channel_reduce_kernel(const char* __restrict__ y, int y_ld, const char* __restri
 #pragma unroll
             for (int e = 0; e < N; ++e) part[(size_t)gridDim.x * 2 * C + v * N + e] = (double)piv[e];
     }
-    for (size_t p = p0 + r; p < p1; p += rows) {
-        float a[N];
-        Vec<DT>::load(y + (p * y_ld) * ES + v * 16, a);
-        if (MODE == 0) {
+    // four pixels per trip: their loads are independent, so each thread keeps 4 (MODE 1: 8) 16-byte
+    // loads in flight
+    for (size_t pb = p0 + r; pb < p1; pb += (size_t)4 * rows) {
+        float a[4][N], g[MODE == 1 ? 4 : 1][N];
+        bool ok[4];
 #pragma unroll
-            for (int e = 0; e < N; ++e) { const float d = a[e] - piv[e]; s0[e] += d; s1[e] += d * d; }
-        } else if (MODE == 1) {
-            float g[N];
-            Vec<DT>::load(dact + (p * d_ld) * ES + v * 16, g);
-#pragma unroll
-            for (int e = 0; e < N; ++e) {
-                const float dz = g[e] * silu_grad((a[e] - mu[e]) * sc[e] + sh[e]);
-                s0[e] += dz;
-                s1[e] += dz * ((a[e] - mu[e]) * is[e]);
+        for (int u = 0; u < 4; ++u) {
+            const size_t p = pb + (size_t)u * rows;
+            ok[u] = p < p1;
+            if (ok[u]) {
+                Vec<DT>::load(y + (p * y_ld) * ES + v * 16, a[u]);
+                if (MODE == 1) Vec<DT>::load(dact + (p * d_ld) * ES + v * 16, g[u]);
             }
-        } else {
+        }
 #pragma unroll
-            for (int e = 0; e < N; ++e) s0[e] += a[e];
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < N; ++e) { const float d = a[u][e] - piv[e]; s0[e] += d; s1[e] += d * d; }
+            } else if (MODE == 1) {
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    const float dz = g[u][e] * silu_grad((a[u][e] - mu[e]) * sc[e] + sh[e]);
+                    s0[e] += dz;
+                    s1[e] += dz * ((a[u][e] - mu[e]) * is[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < N; ++e) s0[e] += a[u][e];
+            }
         }
     }
     float* mine = red + ((size_t)(r * vecs + v) * 2) * N;
@@ -615,21 +628,30 @@ __global__ void __launch_bounds__(256) conv_wgrad_bf16_kernel(WgradP p) {
         }
 }
 
-// dw[i] += sum over slices (fixed order).  Workgroup: 32 elements x 8 slice groups.
-__global__ void __launch_bounds__(256) wgrad_fold_kernel(const float* __restrict__ part, size_t slice, int nslices,
-                                                         float* __restrict__ dw) {
-    __shared__ float red[8][32];
+// dw[i] += sum over slices (fixed order).  Workgroup: 32 elements x G slice groups (G = 32 when there
+// are hundreds of slices, so that no thread walks more than a few dozen dependent additions).
+template <int G>
+__global__ void __launch_bounds__(32 * G) wgrad_fold_kernel(const float* __restrict__ part, size_t slice, int nslices,
+                                                            float* __restrict__ dw) {
+    __shared__ float red[G][32];
     const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
     const size_t i = (size_t)blockIdx.x * 32 + e;
     float s = 0.f;
-    if (i < slice)
-        for (int k = g; k < nslices; k += 8) s += part[(size_t)k * slice + i];
+    if (i < slice) {
+        int k = g;
+        for (; k + 3 * G < nslices; k += 4 * G) {        // four independent loads in flight
+            const float a = part[(size_t)k * slice + i], b = part[(size_t)(k + G) * slice + i];
+            const float c = part[(size_t)(k + 2 * G) * slice + i], d = part[(size_t)(k + 3 * G) * slice + i];
+            s += a; s += b; s += c; s += d;
+        }
+        for (; k < nslices; k += G) s += part[(size_t)k * slice + i];
+    }
     red[g][e] = s;
     __syncthreads();
     if (g == 0 && i < slice) {
         float t = red[0][e];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) t += red[k][e];
+        for (int k = 1; k < G; ++k) t += red[k][e];
         dw[i] += t;
     }
 }
@@ -1110,7 +1132,10 @@ int odamd_conv_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* 
     }
     int err = (int)hipGetLastError();
     if (err) return err;
-    wgrad_fold_kernel<<<(unsigned)((o.p.slice + 31) / 32), 256, 0, st>>>(o.p.part, o.p.slice, o.nslices, dw);
+    if (o.nslices >= 256)
+        wgrad_fold_kernel<32><<<(unsigned)((o.p.slice + 31) / 32), 1024, 0, st>>>(o.p.part, o.p.slice, o.nslices, dw);
+    else
+        wgrad_fold_kernel<8><<<(unsigned)((o.p.slice + 31) / 32), 256, 0, st>>>(o.p.part, o.p.slice, o.nslices, dw);
     return (int)hipGetLastError();
 }
 
