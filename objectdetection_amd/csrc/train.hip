@@ -628,6 +628,107 @@ __global__ void __launch_bounds__(256) conv_wgrad_bf16_kernel(WgradP p) {
         }
 }
 
+// First layer (3 input channels, 3x3, stride 1): the 27 (tap, channel) pairs are the N dimension of
+// ONE 32x32 MFMA tile (im2col in the LDS address of each lane) instead of nine tiles that are 3/32
+// full.  x is the NHWC image padded to 8 channels.  Four waves split the pixels of a patch; slices and
+// fold as in the general kernels.
+template <int DT>
+__global__ void __launch_bounds__(256) conv_wgrad_first_kernel(WgradP p) {
+    constexpr int ES = DT == ODAMD_DTYPE_F32 ? 4 : 2;
+    constexpr int KSTEP = DT == ODAMD_DTYPE_F32 ? 2 : 16;   // pixels per MFMA
+    constexpr int KL = KSTEP / 2;                            // pixels per lane half
+    extern __shared__ __attribute__((aligned(16))) char wl8[];
+    const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+    const int pair = slot % p.npairs, split = (slot / p.npairs) * 8 + xcd;
+    if (split >= p.nsplit) return;
+    const int npix = p.npix, nhalo = p.IH * p.IW;
+    int* tab = (int*)wl8;                                    // [npix] halo pixel index of tap (0,0)
+    char* dyl = wl8 + (size_t)npix * 4;                      // [npix][32] elements
+    char* xl = dyl + (size_t)npix * 32 * ES;                 // [nhalo + 1][8] elements, last pixel all zero
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, kk = lane >> 5;
+    const int co0 = pair * 32;
+    const int nco = min(32, p.Cout - co0);
+    // lane's im2col column: n = tap * Cin + c
+    const int tap = col / p.Cin, c = col - tap * p.Cin;
+    const bool live = col < 9 * p.Cin;
+    const int lane_off = live ? ((tap / 3) * p.IW + (tap % 3)) * 8 + c : 0;
+    for (int q = tid; q < npix; q += 256) {
+        const int ty = q / p.TW, tx = q - ty * p.TW;
+        tab[q] = ty < p.TH ? ty * p.IW + tx : nhalo;
+    }
+    f32x16_t acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    const int steps = npix / KSTEP;
+    const int s0 = wave * (steps / 4), s1 = s0 + steps / 4;
+    for (int t = split; t < p.ntiles; t += p.nsplit) {
+        const int b = t / (p.tiles_x * p.tiles_y), tt = t % (p.tiles_x * p.tiles_y);
+        const int oy0 = (tt / p.tiles_x) * p.TH, ox0 = (tt % p.tiles_x) * p.TW;
+        __syncthreads();
+        constexpr int PPP = 32 * ES / 16;                    // 16-byte pieces per dY pixel
+        for (int i = tid; i < npix * PPP; i += 256) {
+            const int pix = i / PPP, part = i % PPP;
+            const int ty = pix / p.TW, tx = pix - ty * p.TW;
+            const int oy = oy0 + ty, ox = ox0 + tx;
+            const int per = 16 / ES;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (ty < p.TH && oy < p.Ho && ox < p.Wo && part * per < nco) {
+                v = *(const uint4*)((const char*)p.dy + ((((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0 + part * per) * ES);
+                if (part * per + per > nco) {
+                    if constexpr (DT == ODAMD_DTYPE_F32) {
+                        const int valid = nco - part * per;
+                        if (valid < 2) v.y = 0u;
+                        if (valid < 3) v.z = 0u;
+                        v.w = 0u;
+                    } else {
+                        v = mask_bf16x8(v, nco - part * per);
+                    }
+                }
+            }
+            *(uint4*)(dyl + ((size_t)pix * 32 + part * per) * ES) = v;
+        }
+        const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+        constexpr int XPP = 8 * ES / 16;                     // pieces per image pixel (8 channels)
+        for (int i = tid; i < (nhalo + 1) * XPP; i += 256) {
+            const int pix = i / XPP, part = i % XPP;
+            const int hy = pix / p.IW;
+            const int gy = iy0 + hy, gx = ix0 + pix - hy * p.IW;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (pix < nhalo && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                v = *(const uint4*)((const char*)p.x + ((((size_t)b * p.H + gy) * p.W + gx) * p.x_ld) * ES + part * 16);
+            *(uint4*)(xl + ((size_t)pix * 8) * ES + part * 16) = v;
+        }
+        __syncthreads();
+        for (int s = s0; s < s1; ++s) {
+            const int q0 = KSTEP * s + KL * kk;
+            if constexpr (DT == ODAMD_DTYPE_F32) {
+                const float a = ((const float*)dyl)[q0 * 32 + col];
+                const float bv = live ? ((const float*)xl)[tab[q0] * 8 + lane_off] : 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+            } else {
+                const int4 t0 = *(const int4*)(tab + q0), t1 = *(const int4*)(tab + q0 + 4);
+                const int xo[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                bf16x8_t a, bv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    a[e] = (short)((const uint16_t*)dyl)[(q0 + e) * 32 + col];
+                    bv[e] = live ? (short)((const uint16_t*)xl)[xo[e] * 8 + lane_off] : (short)0;
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc, 0, 0, 0);
+            }
+        }
+    }
+    float* out = p.part + ((size_t)split * 4 + wave) * p.slice;
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co0 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+            if (co < p.Cout) out[((size_t)co * p.Cin + c) * 9 + tap] = acc[e];
+        }
+    }
+}
+
 // dw[i] += sum over slices (fixed order).  Workgroup: 32 elements x G slice groups (G = 32 when there
 // are hundreds of slices, so that no thread walks more than a few dozen dependent additions).
 template <int G>
@@ -899,6 +1000,7 @@ struct WgradPlan {
     int wco, wci, r;
     size_t lds;
     int grid, nslices;
+    bool first;            // Cin <= 3, 3x3 stride 1: im2col kernel
 };
 
 // Tile shape, patch shape and split count of one weight-gradient launch.
@@ -911,10 +1013,12 @@ int wgrad_plan(int batch, int h, int w, int cin, int cout, int ksize, int stride
     const int pad = (ksize - 1) / 2, taps = ksize * ksize;
     p.Ho = (h + 2 * pad - ksize) / stride + 1;
     p.Wo = (w + 2 * pad - ksize) / stride + 1;
-    if (ksize == 3) { o.r = 1; o.wco = cout > 32 ? 2 : 1; o.wci = cin > 32 ? 2 : 1; }
+    o.first = ksize == 3 && stride == 1 && cin <= 3;
+    if (o.first) { o.r = 1; o.wco = 1; o.wci = 1; }
+    else if (ksize == 3) { o.r = 1; o.wco = cout > 32 ? 2 : 1; o.wci = cin > 32 ? 2 : 1; }
     else if (cout <= 32 && cin <= 32) { o.r = 1; o.wco = 1; o.wci = 1; }
     else { o.r = 2; o.wco = cout > 64 ? 2 : 1; o.wci = cin > 64 ? 2 : 1; }
-    const int co_t = 32 * o.wco * o.r, ci_t = 32 * o.wci * o.r;
+    const int co_t = 32 * o.wco * o.r, ci_t = o.first ? 8 : 32 * o.wci * o.r;
     // patch width: the largest divisor of the row length in [8, 40], else 32 with guarded edges
     p.TW = 0;
     for (int d = p.Wo < 40 ? p.Wo : 40; d >= 8; --d)
@@ -929,14 +1033,14 @@ int wgrad_plan(int batch, int h, int w, int cin, int cout, int ksize, int stride
         p.npix = (p.TH * p.TW + round - 1) / round * round;
         p.IH = (p.TH - 1) * stride + ksize;
         p.IW = (p.TW - 1) * stride + ksize;
-        o.lds = ((size_t)p.npix * co_t + (size_t)p.IH * p.IW * ci_t) * es + (size_t)p.npix * sizeof(int);
+        o.lds = ((size_t)p.npix * co_t + ((size_t)p.IH * p.IW + 1) * ci_t) * es + (size_t)p.npix * sizeof(int);
         if (o.lds <= 64 * 1024 || p.TH == 1) break;
     }
     if (o.lds > 160 * 1024) return ODAMD_E_SHAPE;
     p.tiles_x = (p.Wo + p.TW - 1) / p.TW;
     p.tiles_y = (p.Ho + p.TH - 1) / p.TH;
     p.ntiles = batch * p.tiles_x * p.tiles_y;
-    p.ncin = (cin + ci_t - 1) / ci_t;
+    p.ncin = o.first ? 1 : (cin + ci_t - 1) / ci_t;
     p.npairs = p.ncin * ((cout + co_t - 1) / co_t);
     int nsplit = (512 + p.npairs - 1) / p.npairs;          // about two workgroups per CU
     nsplit = (nsplit + 7) & ~7;
@@ -1121,7 +1225,11 @@ int odamd_conv_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* 
     o.p.x = x; o.p.dy = dy; o.p.part = (float*)workspace;
     o.p.x_ld = x_ld; o.p.dy_ld = dy_ld;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == ODAMD_DTYPE_F32) {
+    if (o.first) {
+        if ((x_ld * (dtype == ODAMD_DTYPE_F32 ? 4 : 2)) % 16 || x_ld < 8) return ODAMD_E_ALIGN;   // image padded to 8 channels
+        if (dtype == ODAMD_DTYPE_F32) conv_wgrad_first_kernel<ODAMD_DTYPE_F32><<<o.grid, 256, o.lds, st>>>(o.p);
+        else conv_wgrad_first_kernel<ODAMD_DTYPE_BF16><<<o.grid, 256, o.lds, st>>>(o.p);
+    } else if (dtype == ODAMD_DTYPE_F32) {
         if (ksize == 1) wgrad_launch<ODAMD_DTYPE_F32, 1, 1>(o, st);
         else if (stride == 1) wgrad_launch<ODAMD_DTYPE_F32, 3, 1>(o, st);
         else wgrad_launch<ODAMD_DTYPE_F32, 3, 2>(o, st);
