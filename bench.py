@@ -42,6 +42,9 @@ def parse():
     p.add_argument('--train-classes', type=int, default=5)
     p.add_argument('--train-steps', type=int, default=None, help='default: --steps')
     p.add_argument('--no-train', action='store_true', help='skip the training leg')
+    p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                   help='process-group backend (gloo + --share-gpu rehearses the multi-rank path on a one-GPU box)')
+    p.add_argument('--share-gpu', action='store_true', help='every rank uses cuda:0 (rehearsal only)')
     return p.parse_args()
 
 
@@ -77,12 +80,14 @@ def train_leg(a, dev, rank, world, dist, steps, warmup, amp=False):
     targs = patterns.default_args(input_size=a.size, output_class=a.train_classes)
     targs.__dict__.update(device=f'cuda:{dev.index}', batch=a.train_batch, epoch=1, lr_start=0.001, lr_end_ratio=0.1,
                           lr_end_epoch=100, warmup_ratio=0.01, regularization='L2', r_value=0.0005, ema=True,
-                          distributed=world > 1, local_rank=rank, weight_path='', weight_again=True, amp=amp,
+                          distributed=world > 1 and not os.environ.get('BENCH_NO_REDUCER'), local_rank=rank, weight_path='', weight_again=True, amp=amp,
                           print_info=False, save_path=None)
     torch.manual_seed(999)
     ds = synthetic_dataset(targs, a.train_batch * world, seed=999)
     batch = ds.collate_fn([ds[rank * a.train_batch + i] for i in range(a.train_batch)])
+    note('dataset ready')
     tc = train_class(targs, dataloader=[batch] * 1000)
+    note('train_class built')
     tc.optimizer.ema = True                      # every rank carries the EMA so that ranks do equal work
     tc.model.train_state().enable_ema()
     tc.model.train()
@@ -101,6 +106,7 @@ def train_leg(a, dev, rank, world, dist, steps, warmup, amp=False):
         if first is None:
             first = l.tolist()
     fence()
+    note('train warm-up done')
     t0 = time.perf_counter()
     for _ in range(steps):
         l = tc.train_step(image, screen, expend)
@@ -111,6 +117,8 @@ def train_leg(a, dev, rank, world, dist, steps, warmup, amp=False):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     last = l.tolist()
+    if not all(v == v and abs(v) < 1e30 for v in last):
+        raise RuntimeError(f'training leg diverged (amp={amp}): losses {last}')
     return {'images_per_sec': world * a.train_batch * steps / dt, 'ms_per_step': dt / steps * 1e3,
             'global_batch': world * a.train_batch, 'dtype': 'bf16 (f32 accumulate / statistics / master weights)' if amp else 'f32',
             'classes': a.train_classes, 'steps': steps,
@@ -119,20 +127,34 @@ def train_leg(a, dev, rank, world, dist, steps, warmup, amp=False):
             'loss_first': first, 'loss_last': last, 'params': tc.model.train_state().n}, tc
 
 
+def note(msg):
+    """Progress line on stderr (BENCH_DEBUG=1): shows which phase a multi-rank run is in."""
+    if os.environ.get('BENCH_DEBUG'):
+        print(f"[bench rank {os.environ.get('RANK', 0)} +{time.perf_counter():.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     a = parse()
+    if os.environ.get('BENCH_DEBUG'):
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ.get('BENCH_DEBUG_DUMP_S', '90')), exit=False)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != a.gpus and rank == 0:
         print(f'# note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
+    if a.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if a.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group('gloo')
 
     from objectdetection_amd import engine, postprocess
     from objectdetection_amd.model.yolov7 import yolov7
@@ -160,9 +182,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    note('process group up, model built')
     for _ in range(a.warmup):
         res = step()
     fence()
+    note('warm-up done')
     t0 = time.perf_counter()
     for _ in range(a.steps):
         res = step()
@@ -173,6 +197,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     value = world * a.batch * a.steps / dt
+    note(f'inference timed: {dt:.3f}s')
 
     out = None
     if rank == 0:
@@ -253,7 +278,9 @@ def main():
         guard.start()
         del model, x
         tsteps = a.train_steps if a.train_steps is not None else a.steps
+        note('training leg f32')
         train, tc_ = train_leg(a, dev, rank, world, dist, tsteps, max(a.warmup, 2))
+        note('training leg bf16')
         del tc_
         torch.cuda.empty_cache()
         train_amp, tc_ = train_leg(a, dev, rank, world, dist, tsteps, max(a.warmup, 2), amp=True)

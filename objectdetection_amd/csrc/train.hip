@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_first_kernel(WgradP p) {
     const int npix = p.npix, nhalo = p.IH * p.IW;
     int* tab = (int*)wl8;                                    // [npix] halo pixel index of tap (0,0)
     char* dyl = wl8 + (size_t)npix * 4;                      // [npix][32] elements
-    char* xl = dyl + (size_t)npix * 32 * ES;                 // [nhalo + 1][8] elements, last pixel all zero
+    char* xl = dyl + (size_t)npix * 32 * ES;                 // [nhalo][8] elements
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, kk = lane >> 5;
     const int co0 = pair * 32;
@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_first_kernel(WgradP p) {
     const int lane_off = live ? ((tap / 3) * p.IW + (tap % 3)) * 8 + c : 0;
     for (int q = tid; q < npix; q += 256) {
         const int ty = q / p.TW, tx = q - ty * p.TW;
-        tab[q] = ty < p.TH ? ty * p.IW + tx : nhalo;
+        tab[q] = ty < p.TH ? ty * p.IW + tx : 0;     // padding pixels: dY is zero there, any staged (finite) x will do
     }
     f32x16_t acc;
 #pragma unroll
@@ -690,12 +690,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_first_kernel(WgradP p) {
         }
         const int iy0 = oy0 - 1, ix0 = ox0 - 1;
         constexpr int XPP = 8 * ES / 16;                     // pieces per image pixel (8 channels)
-        for (int i = tid; i < (nhalo + 1) * XPP; i += 256) {
+        for (int i = tid; i < nhalo * XPP; i += 256) {
             const int pix = i / XPP, part = i % XPP;
             const int hy = pix / p.IW;
             const int gy = iy0 + hy, gx = ix0 + pix - hy * p.IW;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (pix < nhalo && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
                 v = *(const uint4*)((const char*)p.x + ((((size_t)b * p.H + gy) * p.W + gx) * p.x_ld) * ES + part * 16);
             *(uint4*)(xl + ((size_t)pix * 8) * ES + part * 16) = v;
         }

@@ -10,6 +10,8 @@ further flat buffers updated by one fused launch (train_class.py:158-167, :477-4
 """
 import ctypes as C
 import math
+import os
+import sys
 
 import torch
 
@@ -105,9 +107,12 @@ class GradReducer:
         self.dist, self.group, self.flat = dist, group, flat_grad
         n = flat_grad.numel()
         per = -(-n // n_buckets)
+        if per >= 65536:
+            per = -(-per // 1024) * 1024                     # large buffers: 4 KiB aligned bucket starts
         self.bounds = [(i * per, min(n, (i + 1) * per)) for i in range(n_buckets) if i * per < n]
         self.handles = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.host_staged = dist.is_initialized() and dist.get_backend(group) == 'gloo' and flat_grad.is_cuda
 
     def bucket_of(self, offset):
         for i, (a, b) in enumerate(self.bounds):
@@ -118,6 +123,10 @@ class GradReducer:
     def ready(self, i):
         if self.world > 1:
             a, b = self.bounds[i]
+            if self.host_staged:
+                # gloo stages CUDA tensors through the host and was seen to stall when the stream still
+                # has work queued behind the bucket; RCCL (the production backend) is stream ordered
+                torch.cuda.current_stream().synchronize()
             self.handles.append(self.dist.all_reduce(self.flat[a:b], op=self.dist.ReduceOp.SUM, group=self.group,
                                                      async_op=True))
 
