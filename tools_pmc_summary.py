@@ -18,6 +18,9 @@ def load(path):
 
 
 def family(name):
+    m = re.search(r'conv1x1_stream_kernel<(\d+), (\d+),', name)
+    if m:
+        return 'conv1x1_s1_%s' % {1: 'c32', 2: 'c64', 4: 'c128'}[int(m.group(2))]
     m = re.search(r'conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+),', name)
     if not m:
         return None
