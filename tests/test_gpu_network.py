@@ -50,7 +50,8 @@ BLOCK_CASES = [
     ('elan', dict(in_=32, out_=64, n=2), (1, 32, 16, 16)),
     ('elan_h', dict(in_=64, out_=32), (2, 64, 8, 8)),
     ('mp', dict(in_=32, out_=64), (2, 32, 16, 16)),
-    ('sppcspc', dict(in_=64, out_=32), (2, 64, 20, 20)),
+    ('sppcspc', dict(in_=64, out_=32), (2, 64, 20, 20)),      # plane fits LDS: cascaded 5x5 pools
+    ('sppcspc', dict(in_=32, out_=32), (1, 32, 48, 48)),      # larger plane: direct 13x13 walk
 ]
 
 
