@@ -96,10 +96,13 @@ def test_postprocess_heads_equals_materialised(pp):
         assert np.array_equal(ra, rb)
 
 
-def test_full_size_properties(pp):
-    """25 200 rows/image (640^2 grid), conf 0.001: properties that pin greedy NMS at any size."""
-    r, ncls, thr = 25200, 80, 0.5
-    pred = _synthetic_pred(7, r, ncls, 640, dense=False)
+@pytest.mark.parametrize('r,size', [(25200, 640), (100800, 1280)])
+def test_full_size_properties(pp, r, size):
+    """25 200 rows/image (640^2 grid) and 100 800 rows/image (1280^2, the dense-candidate stress
+    configuration: the suppression mask is processed in row chunks), conf 0.001: properties that pin
+    greedy NMS at any size."""
+    ncls, thr = 80, 0.5
+    pred = _synthetic_pred(7, r, ncls, size, dense=False)
     pred[:, 2:4] *= 0.25
     res = pp.postprocess(torch.from_numpy(pred[None]).cuda(), 0.001, thr)
     rows, kept = res.per_image()[0]
