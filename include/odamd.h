@@ -227,6 +227,27 @@ int odamd_detection_loss(const float* pred, float* dpred, const int* screen, con
                          const float* label, int batch, int rows, int kdim, int n_pos, float label_smooth,
                          float* out4, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same with the number of positives read on the device: n_pos_dev[0] entries (clamped to `capacity`,
+ * the allocated length of screen / screen_img / label) -- the output of odamd_assign_labels; no host
+ * synchronisation between label assignment and loss. */
+int odamd_detection_loss_dev(const float* pred, float* dpred, const int* screen, const int* screen_img,
+                             const float* label, int batch, int rows, int kdim, const int* n_pos_dev, int capacity,
+                             float label_smooth, float* out4, void* workspace, size_t workspace_bytes, void* stream);
+
+/* torch_dataset label -> grid-row assignment (train_class.py:537-543 ranges = decode(-4) .. decode(+4) of
+ * every grid row, :578-607 strict containment of the label's cx, cy, w, h) for a whole batch on the
+ * device.  geometry: grid sizes, strides and anchors as for odamd_decode (head pointers ignored, kdim =
+ * K); sig_lo / sig_hi: sigmoid(-4), sigmoid(+4) as float32; labels: (batch, lmax, K) float32 rows
+ * (cx, cy, w, h, conf, classes...), n_label[b] of them valid.  A row matched by several labels is
+ * emitted once per label, every copy carrying the last matching label (what the reference's loop does:
+ * its conflict branch never runs).  Output in the reference's order (image, then ascending row):
+ * screen[i], screen_img[i], label_out (i, K); n_pos[0] = entries written (<= capacity), n_pos[1] =
+ * entries found; totals: (batch) ints of scratch. */
+int odamd_assign_labels(const odamd_decode_desc* geometry, float sig_lo, float sig_hi, const float* labels,
+                        const int* n_label, int lmax, int* screen, int* screen_img, float* label_out, int capacity,
+                        int* n_pos, int* totals, void* stream);
+
+
 /* torch.optim.Adam with coupled L2 (train_class.py:161-162) over flat float32 buffers, fused with
  * model_ema.update (train_class.py:485-493) when ema != NULL.  step counts from 1; grad_scale
  * multiplies the gradient first (1/world_size after a summing all-reduce).  Hyper-parameters are

@@ -95,6 +95,98 @@ __global__ void __launch_bounds__(256) decode_bwd_kernel(DecodeGeom g, const flo
 }
 
 // ------------------------------------------------------------------------------------------
+// Label -> grid-row assignment of torch_dataset (train_class.py:537-543, :578-607) for a batch.
+// A grid row can express boxes between decode(-4) and decode(+4) of its cell and anchor; a label
+// is assigned to every row whose range strictly contains its (cx, cy, w, h).  The reference's
+// conflict branch never runs (its `label_set` stays empty), so a row matched by several labels is
+// listed once per label and every copy carries the LAST matching label.  Output order = the
+// reference's: images in order, rows ascending within an image.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void row_range(const DecodeGeom& g, int r, float t_lo, float t_hi, float* lo, float* hi) {
+    int s = 0;
+    if (r >= g.rows_before[2]) s = 2; else if (r >= g.rows_before[1]) s = 1;
+    const int lr = r - g.rows_before[s], hw = g.h[s] * g.w[s];
+    const int a = lr / hw, cell = lr - a * hw;
+    const int y = cell / g.w[s], x = cell - y * g.w[s];
+    lo[0] = (2.0f * t_lo - 0.5f + (float)x) * g.stride[s];  hi[0] = (2.0f * t_hi - 0.5f + (float)x) * g.stride[s];
+    lo[1] = (2.0f * t_lo - 0.5f + (float)y) * g.stride[s];  hi[1] = (2.0f * t_hi - 0.5f + (float)y) * g.stride[s];
+    lo[2] = (4.0f * (t_lo * t_lo)) * g.anchor[s][a][0];     hi[2] = (4.0f * (t_hi * t_hi)) * g.anchor[s][a][0];
+    lo[3] = (4.0f * (t_lo * t_lo)) * g.anchor[s][a][1];     hi[3] = (4.0f * (t_hi * t_hi)) * g.anchor[s][a][1];
+}
+
+// matches of row r among the labels of its image: count and last matching label
+__device__ __forceinline__ int row_matches(const float* __restrict__ lab, int nl, int kdim, const float* lo, const float* hi,
+                                           int* last) {
+    int cnt = 0;
+    for (int l = 0; l < nl; ++l) {
+        const float* q = lab + (size_t)l * kdim;
+        if (lo[0] < q[0] && q[0] < hi[0] && lo[1] < q[1] && q[1] < hi[1] && lo[2] < q[2] && q[2] < hi[2] &&
+            lo[3] < q[3] && q[3] < hi[3]) { ++cnt; *last = l; }
+    }
+    return cnt;
+}
+
+__device__ __forceinline__ int block_scan_excl(int v, int* sm, int* total) {   // 256 threads
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int t = (int)threadIdx.x >= d ? sm[threadIdx.x - d] : 0;
+        __syncthreads();
+        sm[threadIdx.x] += t;
+        __syncthreads();
+    }
+    const int incl = sm[threadIdx.x];
+    *total = sm[255];
+    __syncthreads();
+    return incl - v;
+}
+
+// EMIT == false: totals[b] = entries of image b.  EMIT == true: writes the entries (needs totals).
+template <bool EMIT>
+__global__ void __launch_bounds__(256)
+assign_labels_kernel(DecodeGeom g, float t_lo, float t_hi, const float* __restrict__ labels, const int* __restrict__ n_label,
+                     int lmax, int* __restrict__ totals, int* __restrict__ screen, int* __restrict__ screen_img,
+                     float* __restrict__ label_out, int capacity, int* __restrict__ n_pos, int batch) {
+    __shared__ int sm[256];
+    const int b = blockIdx.x;
+    const int nl = min(n_label[b], lmax);
+    const float* lab = labels + (size_t)b * lmax * g.kdim;
+    int base = 0;
+    if (EMIT) {
+        for (int i = 0; i < b; ++i) base += totals[i];
+        if (b == batch - 1 && threadIdx.x == 0) {
+            const int all = base + totals[b];
+            n_pos[0] = min(all, capacity);
+            n_pos[1] = all;
+        }
+    }
+    int running = 0;
+    for (int r0 = 0; r0 < g.rows; r0 += 256) {
+        const int r = r0 + threadIdx.x;
+        int cnt = 0, last = 0;
+        if (r < g.rows) {
+            float lo[4], hi[4];
+            row_range(g, r, t_lo, t_hi, lo, hi);
+            cnt = row_matches(lab, nl, g.kdim, lo, hi, &last);
+        }
+        int total;
+        const int off = block_scan_excl(cnt, sm, &total);
+        if (EMIT) {
+            for (int c = 0; c < cnt; ++c) {
+                const int pos = base + running + off + c;
+                if (pos < capacity) {
+                    screen[pos] = r;
+                    screen_img[pos] = b;
+                    for (int k = 0; k < g.kdim; ++k) label_out[(size_t)pos * g.kdim + k] = lab[(size_t)last * g.kdim + k];
+                }
+            }
+        }
+        running += total;
+    }
+    if (!EMIT && threadIdx.x == 0) totals[b] = running;
+}
+
+// ------------------------------------------------------------------------------------------
 // filter: rows -> row boxes + compacted sort keys
 // ------------------------------------------------------------------------------------------
 // Sort key: high word = score bits mapped so that unsigned order == float order, low word = row
@@ -536,11 +628,11 @@ int next_pow2(int v) {
     return p;
 }
 
-int fill_geom(const odamd_decode_desc* d, DecodeGeom* g) {
+int fill_geom(const odamd_decode_desc* d, DecodeGeom* g, bool need_heads = true) {
     if (!d || d->n_anchor < 1 || d->n_anchor > 4 || d->batch < 1 || d->kdim < 6) return ODAMD_E_ARG;
     int rows = 0;
     for (int s = 0; s < 3; ++s) {
-        if (!d->head[s] || d->h[s] < 1 || d->w[s] < 1) return ODAMD_E_ARG;
+        if ((need_heads && !d->head[s]) || d->h[s] < 1 || d->w[s] < 1) return ODAMD_E_ARG;
         g->head[s] = d->head[s];
         g->h[s] = d->h[s];
         g->w[s] = d->w[s];
@@ -691,6 +783,22 @@ int odamd_decode(const odamd_decode_desc* d, float* out, void* stream) {
     int gx = (maxn + 255) / 256;
     if (gx > 2048) gx = 2048;
     decode_kernel<<<dim3(gx, 3, d->batch), 256, 0, (hipStream_t)stream>>>(g, out);
+    return (int)hipGetLastError();
+}
+
+int odamd_assign_labels(const odamd_decode_desc* geometry, float sig_lo, float sig_hi, const float* labels,
+                        const int* n_label, int lmax, int* screen, int* screen_img, float* label_out, int capacity,
+                        int* n_pos, int* totals, void* stream) {
+    DecodeGeom g;
+    int rc = fill_geom(geometry, &g, false);
+    if (rc) return rc;
+    if (!labels || !n_label || !screen || !screen_img || !label_out || !n_pos || !totals || lmax < 1 || capacity < 1)
+        return ODAMD_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    assign_labels_kernel<false><<<geometry->batch, 256, 0, st>>>(g, sig_lo, sig_hi, labels, n_label, lmax, totals, nullptr,
+                                                                 nullptr, nullptr, capacity, n_pos, geometry->batch);
+    assign_labels_kernel<true><<<geometry->batch, 256, 0, st>>>(g, sig_lo, sig_hi, labels, n_label, lmax, totals, screen,
+                                                                screen_img, label_out, capacity, n_pos, geometry->batch);
     return (int)hipGetLastError();
 }
 

@@ -811,7 +811,9 @@ struct LossP {
     double* part;             // [0..nblk) confidence partials, then [nblk..2 nblk) frame, [2 nblk..3 nblk) class
     int nblk;
     float* out;               // (4) loss, frame, confidence, class
+    const int* P_dev;         // when set: positives = min(*P_dev, P) is read on the device (P = capacity)
 };
+__device__ __forceinline__ int loss_npos(const LossP& p) { return p.P_dev ? min(*p.P_dev, p.P) : p.P; }
 
 __device__ __forceinline__ double block_sum(double v, double* sm) {
     sm[threadIdx.x] = v;
@@ -828,7 +830,7 @@ __device__ __forceinline__ double block_sum(double v, double* sm) {
 // Marks the positive rows: dpred[b][r][4] = 1 (a flag consumed and overwritten by the next kernel).
 __global__ void loss_mark_kernel(LossP p) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < p.P) p.dpred[((size_t)p.screen_img[i] * p.R + p.screen[i]) * p.K + 4] = 1.0f;
+    if (i < loss_npos(p)) p.dpred[((size_t)p.screen_img[i] * p.R + p.screen[i]) * p.K + 4] = 1.0f;
 }
 
 // Focal objectness loss over every row (train_class.py:470-474, alpha = 0.5, gamma = 2, x100).
@@ -857,7 +859,8 @@ __global__ void __launch_bounds__(256) loss_pos_kernel(LossP p) {
     __shared__ double sm[256];
     double fa = 0.0, ca = 0.0;
     const int C = p.K - 5;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.P; i += gridDim.x * 256) {
+    const int P = loss_npos(p);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) {
         const size_t row = ((size_t)p.screen_img[i] * p.R + p.screen[i]) * p.K;
         const float* pr = p.pred + row;
         const float* lb = p.label + (size_t)i * p.K;
@@ -865,11 +868,11 @@ __global__ void __launch_bounds__(256) loss_pos_kernel(LossP p) {
         const D4 c = ciou_d4(pr, lb);
         fa += (double)c.v;
         // a row may be listed more than once (the reference's assignment keeps duplicates): add
-        for (int k = 0; k < 4; ++k) atomicAdd(&g[k], -c.d[k] / (float)p.P);   // frame = 1 - mean(ciou)
+        for (int k = 0; k < 4; ++k) atomicAdd(&g[k], -c.d[k] / (float)P);   // frame = 1 - mean(ciou)
         if (C == 1) {                                                  // BCEWithLogitsLoss, mean over P
             const float x = pr[5], y = lb[5];
             ca += (double)(fmaxf(x, 0.0f) - x * y + log1pf(expf(-fabsf(x))));
-            atomicAdd(&g[5], (1.0f / (1.0f + expf(-x)) - y) / (float)p.P);
+            atomicAdd(&g[5], (1.0f / (1.0f + expf(-x)) - y) / (float)P);
         } else {                                                       // CrossEntropyLoss with soft targets
             float m = pr[5];
             for (int k = 1; k < C; ++k) m = fmaxf(m, pr[5 + k]);
@@ -879,7 +882,7 @@ __global__ void __launch_bounds__(256) loss_pos_kernel(LossP p) {
             float l = 0.0f;
             for (int k = 0; k < C; ++k) {
                 l -= lb[5 + k] * (pr[5 + k] - lse);
-                atomicAdd(&g[5 + k], (expf(pr[5 + k] - lse) * ts - lb[5 + k]) / (float)p.P);
+                atomicAdd(&g[5 + k], (expf(pr[5 + k] - lse) * ts - lb[5 + k]) / (float)P);
             }
             ca += (double)l;
         }
@@ -896,7 +899,8 @@ __global__ void loss_finalize_kernel(LossP p, int nconf, int npos) {
     for (int i = 0; i < npos; ++i) { f += p.part[p.nblk + i]; k += p.part[2 * p.nblk + i]; }
     const float conf = (float)(100.0 * c / ((double)p.B * p.R));
     float frame = 1.0f, cls = 1.0f;                                     // no positives: constants
-    if (p.P > 0) { frame = (float)(1.0 - f / p.P); cls = (float)(k / p.P); }
+    const int P = loss_npos(p);
+    if (P > 0) { frame = (float)(1.0 - f / P); cls = (float)(k / P); }
     p.out[0] = frame + conf + cls;
     p.out[1] = frame;
     p.out[2] = conf;
@@ -1249,14 +1253,15 @@ int odamd_conv_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* 
 
 size_t odamd_loss_workspace_bytes(void) { return (size_t)3 * 1024 * sizeof(double); }
 
-int odamd_detection_loss(const float* pred, float* dpred, const int* screen, const int* screen_img, const float* label,
-                         int batch, int rows, int kdim, int n_pos, float label_smooth, float* out4, void* workspace,
-                         size_t workspace_bytes, void* stream) {
+static int loss_launch(const float* pred, float* dpred, const int* screen, const int* screen_img, const float* label,
+                       int batch, int rows, int kdim, int n_pos, const int* n_pos_dev, float label_smooth, float* out4,
+                       void* workspace, size_t workspace_bytes, void* stream) {
     if (!pred || !dpred || !out4 || !workspace || batch < 1 || rows < 1 || kdim < 6 || n_pos < 0) return ODAMD_E_ARG;
     if (n_pos > 0 && (!screen || !screen_img || !label)) return ODAMD_E_ARG;
     if (workspace_bytes < odamd_loss_workspace_bytes()) return ODAMD_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    LossP p = {pred, dpred, screen, screen_img, label, batch, rows, kdim, n_pos, label_smooth, (double*)workspace, 1024, out4};
+    LossP p = {pred, dpred, screen, screen_img, label, batch, rows, kdim, n_pos, label_smooth, (double*)workspace, 1024, out4,
+               n_pos_dev};
     int rc = (int)hipMemsetAsync(dpred, 0, (size_t)batch * rows * kdim * sizeof(float), st);
     if (rc) return rc;
     if (n_pos > 0) loss_mark_kernel<<<(n_pos + 255) / 256, 256, 0, st>>>(p);
@@ -1271,6 +1276,21 @@ int odamd_detection_loss(const float* pred, float* dpred, const int* screen, con
     }
     loss_finalize_kernel<<<1, 64, 0, st>>>(p, nconf, npos);
     return (int)hipGetLastError();
+}
+
+int odamd_detection_loss(const float* pred, float* dpred, const int* screen, const int* screen_img, const float* label,
+                         int batch, int rows, int kdim, int n_pos, float label_smooth, float* out4, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    return loss_launch(pred, dpred, screen, screen_img, label, batch, rows, kdim, n_pos, nullptr, label_smooth, out4,
+                       workspace, workspace_bytes, stream);
+}
+
+int odamd_detection_loss_dev(const float* pred, float* dpred, const int* screen, const int* screen_img, const float* label,
+                             int batch, int rows, int kdim, const int* n_pos_dev, int capacity, float label_smooth,
+                             float* out4, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!n_pos_dev || capacity < 1) return ODAMD_E_ARG;
+    return loss_launch(pred, dpred, screen, screen_img, label, batch, rows, kdim, capacity, n_pos_dev, label_smooth, out4,
+                       workspace, workspace_bytes, stream);
 }
 
 int odamd_adam_ema_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, size_t n, double lr,

@@ -46,7 +46,8 @@ class loss_class:
         self.output_size = args.output_size
         self.label_smooth = args.label_smooth
 
-    def __call__(self, pred, screen_list, label_expend):
+    def __call__(self, pred, screen_list, label_expend=None):
+        """`screen_list` may also be a DeviceAssignment (then `label_expend` is not used)."""
         plan = getattr(pred, '_odamd_plan', None)
         if plan is None:
             raise RuntimeError('loss_class needs the prediction of a training-mode objectdetection_amd yolov7')
@@ -183,6 +184,72 @@ def assign_labels(label, range_floor, range_upper):
     last.scatter_reduce_(0, rows, li, 'amax', include_self=True)
     rows_sorted, _ = torch.sort(rows)
     return rows_sorted, label[last[rows_sorted]]
+
+
+class DeviceAssignment:
+    """Result of `device_labels`: positives of a batch, all on the GPU (no host copy of the count)."""
+
+    def __init__(self, screen, screen_img, label, n_pos, capacity):
+        self.screen, self.screen_img, self.label, self.n_pos, self.capacity = screen, screen_img, label, n_pos, capacity
+
+    def per_image(self, batch):
+        """Host view in the reference's format: (list of int64 row vectors, concatenated label rows)."""
+        n = int(self.n_pos[0])
+        if int(self.n_pos[1]) > self.capacity:
+            raise RuntimeError(f'label assignment overflow: {int(self.n_pos[1])} entries, capacity {self.capacity}')
+        rows, img = self.screen[:n].cpu().long(), self.screen_img[:n].cpu()
+        return [rows[img == b] for b in range(batch)], self.label[:n].cpu()
+
+
+class device_labels:
+    """Label -> grid-row assignment of torch_dataset (train_class.py:537-543, :578-607) for whole
+    batches on the GPU (odamd_assign_labels).  __call__(labels) takes one (L_b, K) float32 tensor per
+    image (cx, cy, w, h, conf, classes..., already smoothed) and returns a DeviceAssignment that
+    `loss_class` accepts in place of (screen_list, label_expend)."""
+
+    def __init__(self, args, lmax=64, capacity=None):
+        from ._lib import DecodeDesc
+        self.args, self.lmax = args, lmax
+        self.k = 5 + args.output_class
+        d = DecodeDesc()
+        anc = (args.input_size * torch.tensor(args.anchor, dtype=torch.float32)).tolist()
+        for i, hw in enumerate(args.output_size):
+            d.h[i] = d.w[i] = hw
+            d.stride[i] = args.input_size / hw
+            for j in range(args.output_layer[i]):
+                d.anchor_px[i][j][0], d.anchor_px[i][j][1] = anc[i][j][0], anc[i][j][1]
+        d.n_anchor, d.kdim, d.deploy = args.output_layer[0], self.k, 0
+        self.desc = d
+        self.sig_lo = float(torch.sigmoid(torch.tensor(-4.0)))
+        self.sig_hi = float(torch.sigmoid(torch.tensor(4.0)))
+        self.capacity = capacity
+
+    def __call__(self, labels, device='cuda'):
+        import ctypes as C
+        from ._lib import lib, check
+        b = len(labels)
+        cap = self.capacity or b * self.lmax * 64
+        packed = torch.zeros((b, self.lmax, self.k), dtype=torch.float32)
+        counts = torch.zeros(b, dtype=torch.int32)
+        for i, lab in enumerate(labels):
+            if len(lab) > self.lmax:
+                raise ValueError(f'{len(lab)} labels in one image, lmax is {self.lmax}')
+            packed[i, :len(lab)] = lab
+            counts[i] = len(lab)
+        packed, counts = packed.to(device, non_blocking=True), counts.to(device, non_blocking=True)
+        screen = torch.empty(cap, dtype=torch.int32, device=device)
+        simg = torch.empty(cap, dtype=torch.int32, device=device)
+        out = torch.empty((cap, self.k), dtype=torch.float32, device=device)
+        n_pos = torch.zeros(2, dtype=torch.int32, device=device)
+        totals = torch.empty(b, dtype=torch.int32, device=device)
+        self.desc.batch = b
+        check(lib.odamd_assign_labels(C.byref(self.desc), self.sig_lo, self.sig_hi, packed.data_ptr(), counts.data_ptr(),
+                                      self.lmax, screen.data_ptr(), simg.data_ptr(), out.data_ptr(), cap, n_pos.data_ptr(),
+                                      totals.data_ptr(), te._stream()), 'assign_labels')
+        keep = (packed, counts, totals)        # alive until the stream has consumed them
+        res = DeviceAssignment(screen, simg, out, n_pos, cap)
+        res._keep = keep
+        return res
 
 
 class synthetic_dataset(torch.utils.data.Dataset):

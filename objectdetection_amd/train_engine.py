@@ -451,6 +451,16 @@ class TrainPlan:
     def loss(self, screen_list, label_expend, label_smooth):
         """loss_class.__call__ on the last forward's prediction; fills self.dpred; returns a (4,) tensor."""
         dev = self.dev
+        if hasattr(screen_list, 'n_pos'):        # DeviceAssignment: count stays on the device
+            a = screen_list
+            b, r, k = self.pred.shape
+            self._keep_loss = a
+            check(lib.odamd_detection_loss_dev(self.pred.data_ptr(), self.dpred.data_ptr(), a.screen.data_ptr(),
+                                               a.screen_img.data_ptr(), a.label.data_ptr(), b, r, k, a.n_pos.data_ptr(),
+                                               a.capacity, float(label_smooth), self.loss_out.data_ptr(),
+                                               self.loss_ws.data_ptr(), self.loss_ws.numel(), _stream()),
+                  'detection_loss_dev')
+            return self.loss_out
         idx, img = [], []
         for b, s in enumerate(screen_list):
             if len(s):
