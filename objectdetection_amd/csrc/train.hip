@@ -22,6 +22,19 @@ __device__ __forceinline__ float silu_grad(float z) {
     const float s = 1.0f / (1.0f + expf(-z));
     return s * (1.0f + z * (1.0f - s));
 }
+// bf16 kernels round their results to 8 mantissa bits: hardware exp / reciprocal are plenty
+template <int DT> __device__ __forceinline__ float sigmoid_t(float z) {
+    if constexpr (DT == ODAMD_DTYPE_F32) return 1.0f / (1.0f + expf(-z));
+    else return __frcp_rn(1.0f + __expf(-z));
+}
+template <int DT> __device__ __forceinline__ float silu_t(float z) {
+    if constexpr (DT == ODAMD_DTYPE_F32) return silu_f(z);
+    else return z * sigmoid_t<DT>(z);
+}
+template <int DT> __device__ __forceinline__ float silu_grad_t(float z) {
+    const float s = sigmoid_t<DT>(z);
+    return s * (1.0f + z * (1.0f - s));
+}
 
 template <int DT> struct Vec;
 template <> struct Vec<ODAMD_DTYPE_F32> {
@@ -105,7 +118,7 @@ channel_reduce_kernel(const char* __restrict__ y, int y_ld, const char* __restri
             } else if (MODE == 1) {
 #pragma unroll
                 for (int e = 0; e < N; ++e) {
-                    const float dz = g[u][e] * silu_grad((a[u][e] - mu[e]) * sc[e] + sh[e]);
+                    const float dz = g[u][e] * silu_grad_t<DT>((a[u][e] - mu[e]) * sc[e] + sh[e]);
                     s0[e] += dz;
                     s1[e] += dz * ((a[u][e] - mu[e]) * is[e]);
                 }
@@ -205,46 +218,79 @@ bias_grad_finalize_kernel(const double* __restrict__ part, int nblk, int C, floa
 }
 
 // act = silu((y - mean)*scale + beta), written at a channel offset of a wider buffer (shift holds beta).
+// Thread (v, r) of a workgroup owns the channels of 16-byte vector v for good (its per-channel
+// constants live in registers) and walks pixels r, r + rows, ... of the grid-strided pixel list, four
+// pixels per trip so that their loads overlap.
 template <int DT>
 __global__ void __launch_bounds__(256)
-bn_apply_silu_kernel(const char* __restrict__ y, int y_ld, char* __restrict__ out, int o_ld, size_t npix, int vecs,
+bn_apply_silu_kernel(const char* __restrict__ y, int y_ld, char* __restrict__ out, int o_ld, size_t npix, int vecs, int rows,
                      const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean) {
     constexpr int N = Vec<DT>::N, ES = Vec<DT>::ES;
-    const size_t n = npix * vecs;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int v = i % vecs;
-        const size_t p = i / vecs;
-        float a[N];
-        Vec<DT>::load(y + (p * y_ld) * ES + v * 16, a);
+    const int v = threadIdx.x % vecs, r = threadIdx.x / vecs;
+    if (r >= rows) return;
+    float sc[N], sh[N], mu[N];
 #pragma unroll
-        for (int e = 0; e < N; ++e) a[e] = silu_f((a[e] - mean[v * N + e]) * scale[v * N + e] + shift[v * N + e]);
-        Vec<DT>::store(out + (p * o_ld) * ES + v * 16, a);
+    for (int e = 0; e < N; ++e) { sc[e] = scale[v * N + e]; sh[e] = shift[v * N + e]; mu[e] = mean[v * N + e]; }
+    const size_t step = (size_t)gridDim.x * rows;
+    for (size_t pb = (size_t)blockIdx.x * rows + r; pb < npix; pb += 4 * step) {
+        float a[4][N];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t p = pb + u * step;
+            ok[u] = p < npix;
+            if (ok[u]) Vec<DT>::load(y + (p * y_ld) * ES + v * 16, a[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+#pragma unroll
+            for (int e = 0; e < N; ++e) a[u][e] = silu_t<DT>((a[u][e] - mu[e]) * sc[e] + sh[e]);
+            Vec<DT>::store(out + ((pb + u * step) * o_ld) * ES + v * 16, a[u]);
+        }
     }
 }
 
 // dy = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat)), written over y in place.
 template <int DT>
 __global__ void __launch_bounds__(256)
-bn_bwd_apply_kernel(char* __restrict__ y, int y_ld, const char* __restrict__ dact, int d_ld, size_t npix, int vecs,
+bn_bwd_apply_kernel(char* __restrict__ y, int y_ld, const char* __restrict__ dact, int d_ld, size_t npix, int vecs, int rows,
                     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
                     const float* __restrict__ invstd, const float* __restrict__ mean_dz,
                     const float* __restrict__ mean_dzx) {
     constexpr int N = Vec<DT>::N, ES = Vec<DT>::ES;
-    const size_t n = npix * vecs;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int v = i % vecs;
-        const size_t p = i / vecs;
-        float a[N], g[N];
-        Vec<DT>::load(y + (p * y_ld) * ES + v * 16, a);
-        Vec<DT>::load(dact + (p * d_ld) * ES + v * 16, g);
+    const int v = threadIdx.x % vecs, r = threadIdx.x / vecs;
+    if (r >= rows) return;
+    float sc[N], sh[N], mu[N], is[N], mdz[N], mdx[N];
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-            const int c = v * N + e;
-            const float dz = g[e] * silu_grad((a[e] - mean[c]) * scale[c] + shift[c]);
-            const float xh = (a[e] - mean[c]) * invstd[c];
-            a[e] = scale[c] * (dz - mean_dz[c] - xh * mean_dzx[c]);   // scale = gamma * invstd
+    for (int e = 0; e < N; ++e) {
+        const int c = v * N + e;
+        sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c]; mdz[e] = mean_dz[c]; mdx[e] = mean_dzx[c];
+    }
+    const size_t step = (size_t)gridDim.x * rows;
+    for (size_t pb = (size_t)blockIdx.x * rows + r; pb < npix; pb += 2 * step) {
+        float a[2][N], g[2][N];
+        bool ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const size_t p = pb + u * step;
+            ok[u] = p < npix;
+            if (ok[u]) {
+                Vec<DT>::load(y + (p * y_ld) * ES + v * 16, a[u]);
+                Vec<DT>::load(dact + (p * d_ld) * ES + v * 16, g[u]);
+            }
         }
-        Vec<DT>::store(y + (p * y_ld) * ES + v * 16, a);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!ok[u]) continue;
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                const float dz = g[u][e] * silu_grad_t<DT>((a[u][e] - mu[e]) * sc[e] + sh[e]);
+                const float xh = (a[u][e] - mu[e]) * is[e];
+                a[u][e] = sc[e] * (dz - mdz[e] - xh * mdx[e]);   // scale = gamma * invstd
+            }
+            Vec<DT>::store(y + ((pb + u * step) * y_ld) * ES + v * 16, a[u]);
+        }
     }
 }
 
@@ -991,6 +1037,12 @@ int red_blocks(size_t npix, int rows) {
     return (int)b;
 }
 
+// grid of the (vector, row) elementwise kernels: about eight pixels per thread, at most 4096 workgroups
+int ew_rows_grid(size_t npix, int rows) {
+    size_t g = (npix + (size_t)rows * 8 - 1) / ((size_t)rows * 8);
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
 int ew_grid(size_t n) {
     size_t g = (n + 255) / 256;
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -1106,9 +1158,9 @@ int odamd_bn_train_forward(const void* y, int y_ld, void* out, int out_ld, size_
         channel_reduce_kernel<ODAMD_DTYPE_BF16, 0><<<nblk, vecs * rows, lds, st>>>((const char*)y, y_ld, nullptr, 0, npix, channels, vecs, rows, nullptr, nullptr, nullptr, nullptr, part);
     bn_stats_finalize_kernel<<<(channels + 3) / 4, 256, 0, st>>>(part, nblk, channels, (double)npix, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
     if (dtype == ODAMD_DTYPE_F32)
-        bn_apply_silu_kernel<ODAMD_DTYPE_F32><<<ew_grid(npix * vecs), 256, 0, st>>>((const char*)y, y_ld, (char*)out, out_ld, npix, vecs, scale, shift, mean);
+        bn_apply_silu_kernel<ODAMD_DTYPE_F32><<<ew_rows_grid(npix, rows), vecs * rows, 0, st>>>((const char*)y, y_ld, (char*)out, out_ld, npix, vecs, rows, scale, shift, mean);
     else
-        bn_apply_silu_kernel<ODAMD_DTYPE_BF16><<<ew_grid(npix * vecs), 256, 0, st>>>((const char*)y, y_ld, (char*)out, out_ld, npix, vecs, scale, shift, mean);
+        bn_apply_silu_kernel<ODAMD_DTYPE_BF16><<<ew_rows_grid(npix, rows), vecs * rows, 0, st>>>((const char*)y, y_ld, (char*)out, out_ld, npix, vecs, rows, scale, shift, mean);
     return (int)hipGetLastError();
 }
 
@@ -1133,9 +1185,9 @@ int odamd_bn_silu_backward(void* y_dy, int y_ld, const void* dact, int dact_ld, 
         channel_reduce_kernel<ODAMD_DTYPE_BF16, 1><<<nblk, vecs * rows, lds, st>>>((const char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, channels, vecs, rows, scale, shift, mean, invstd, part);
     bn_bwd_finalize_kernel<<<(channels + 3) / 4, 256, 0, st>>>(part, nblk, channels, (double)npix, dgamma, dbeta, mean_dz, mean_dzx);
     if (dtype == ODAMD_DTYPE_F32)
-        bn_bwd_apply_kernel<ODAMD_DTYPE_F32><<<ew_grid(npix * vecs), 256, 0, st>>>((char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, vecs, scale, shift, mean, invstd, mean_dz, mean_dzx);
+        bn_bwd_apply_kernel<ODAMD_DTYPE_F32><<<ew_rows_grid(npix, rows), vecs * rows, 0, st>>>((char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, vecs, rows, scale, shift, mean, invstd, mean_dz, mean_dzx);
     else
-        bn_bwd_apply_kernel<ODAMD_DTYPE_BF16><<<ew_grid(npix * vecs), 256, 0, st>>>((char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, vecs, scale, shift, mean, invstd, mean_dz, mean_dzx);
+        bn_bwd_apply_kernel<ODAMD_DTYPE_BF16><<<ew_rows_grid(npix, rows), vecs * rows, 0, st>>>((char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, vecs, rows, scale, shift, mean, invstd, mean_dz, mean_dzx);
     return (int)hipGetLastError();
 }
 
