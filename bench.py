@@ -72,7 +72,7 @@ def cpu_baseline(model, a, margs, x_cpu):
 
 
 def train_leg(a, dev, rank, world, dist, steps, warmup, amp=False):
-    """Training step (configs[2]/[3]): forward (batch-statistics BN) + loss + backward + bucketed
+    """Training step (the single-GPU and data-parallel training configurations): forward (batch-statistics BN) + loss + backward + bucketed
     gradient all-reduce (RCCL when world > 1) + fused Adam/EMA, float32 or (amp) bf16 mixed precision, `--train-batch` synthetic
     images per GPU with 8 synthetic boxes each.  Weak scaling: global batch = world * train-batch."""
     from objectdetection_amd.train_class import train_class, synthetic_dataset
@@ -250,7 +250,7 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': f'YOLOv7-s {a.size}x{a.size} batch {a.batch} {a.dtype} inference + GPU decode/NMS '
-                                   f'(BASELINE configs[1]); C={a.classes}, conf {a.conf}, iou {a.iou}',
+                                   f'(headline configuration 2 of 5); C={a.classes}, conf {a.conf}, iou {a.iou}',
                        'global_batch': a.batch * world, 'parallelism': f'replicas x{world}',
                        'pipeline': 'network(i+1) overlaps decode/NMS(i) on two HIP streams'},
             'roofline': roof,
@@ -295,7 +295,7 @@ def main():
                             'value': train['images_per_sec'], 'ms_per_step': train['ms_per_step'], 'dtype': 'f32',
                             'steps': tsteps,
                             'config': {'workload': f'YOLOv7-s {a.size}x{a.size} training step, batch {a.train_batch} per GPU, '
-                                                   f'synthetic labels (BASELINE configs[2]/[3]); C={a.train_classes}',
+                                                   f'synthetic labels (training configurations 3 and 4 of 5); C={a.train_classes}',
                                        'global_batch': train['global_batch'], 'parallelism': train['parallelism']},
                             'infer': infer})
     if dist is not None:

@@ -40,7 +40,7 @@ def test_argument_validation_without_gpu():
 
 
 def test_state_dict_names_match_reference_layout():
-    """474 entries for preset s (SURVEY probe of the reference), fixed key examples."""
+    """474 entries for preset s (counted on the reference's own module), fixed key examples."""
     from objectdetection_amd.model.yolov7 import yolov7
     from oracle import patterns
     m = yolov7(patterns.default_args(input_size=64, output_class=80))

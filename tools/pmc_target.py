@@ -1,9 +1,10 @@
 """Short target for rocprofv3 counter passes: a few batch-64 bf16 640x640 network forwards plus
 post-processing (the bench workload without timing), so one --pmc pass takes seconds."""
+import os
 import sys
 import torch
 
-sys.path.insert(0, __file__.rsplit('/', 1)[0])
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from objectdetection_amd import engine, postprocess          # noqa: E402
 from objectdetection_amd.model.yolov7 import yolov7         # noqa: E402
 from oracle import patterns                                  # noqa: E402
