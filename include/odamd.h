@@ -212,8 +212,9 @@ int odamd_upsample2_backward(const void* dy, int dy_ld, void* dx, int dx_ld, int
  * in the reference's parameter layout, ADDED to.  x: (B,H,W) NHWC input, dy: NHWC gradient of the
  * raw output.  Workgroups store partial sums to `workspace` (odamd_conv_wgrad_workspace_bytes of the
  * same shape) and a second launch folds them into dw in a fixed order: no atomics, the result is
- * reproducible run to run.  dtype: element type of x and dy (float32 on v_mfma_f32_32x32x2_f32, bf16 on
- * v_mfma_f32_32x32x16_bf16); dw and the accumulation are float32 in both. */
+ * reproducible run to run.  dtype: element type of x and dy.  Both run on v_mfma_f32_32x32x16_bf16 with
+ * float32 accumulation and float32 dw; float32 operands are split into hi + lo bf16 parts (three MFMAs
+ * per product, ~2^-17 relative), the 3-channel first layer uses an exact float32 im2col tile. */
 size_t odamd_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int ksize, int stride, int dtype);
 int odamd_conv_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int batch, int h, int w, int cin,
                      int cout, int ksize, int stride, int dtype, void* workspace, size_t workspace_bytes, void* stream);

@@ -426,12 +426,12 @@ upsample2_bwd_kernel(const char* __restrict__ dy, int dy_ld, char* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// Convolution weight gradient, float32 on v_mfma_f32_32x32x2_f32:
+// Convolution weight gradient:
 //   dW[co][ci][ky][kx] = sum_pixels dY[pixel][co] * X[pixel*stride - pad + (ky,kx)][ci]
 // GEMM view: M = output channels, N = input channels (per tap), K = pixels.  A workgroup owns one
 // (co tile, ci tile) pair and every nsplit-th pixel patch; per patch it stages the dY patch
-// [pixels][CO_T] and the X halo patch [halo pixels][CI_T] in LDS (a fragment read is 32 consecutive
-// floats: conflict free) and accumulates all taps in registers.  The four waves are laid out
+// [pixels][CO_T] and the X halo patch [halo pixels][CI_T] in LDS (a fragment read touches 32
+// consecutive channels: conflict free) and accumulates all taps in registers.  The four waves are laid out
 // WCO x WCI over the tile and, when the tile is smaller than four waves, WPX ways over the pixels of
 // a patch.  Each wave keeps R x R MFMA tiles per tap.
 // Every wave stores its sums to its own slice of `part` ([split][pixel group][Cout][Cin][taps], the torch
@@ -446,113 +446,7 @@ struct WgradP {
     size_t slice;
 };
 
-template <int KS, int ST, int WCO, int WCI, int R>
-__global__ void __launch_bounds__(256) conv_wgrad_f32_kernel(WgradP p) {
-    constexpr int TAPS = KS * KS, PAD = (KS - 1) / 2;
-    constexpr int CO_T = 32 * WCO * R, CI_T = 32 * WCI * R, WPX = 4 / (WCO * WCI);
-    constexpr int NACC = TAPS * R * R;
-    constexpr int PCO = CO_T / 4, PCI = CI_T / 4;          // float4 per staged pixel
-    extern __shared__ __attribute__((aligned(16))) float wl[];
-    const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
-    const int pair = slot % p.npairs, split = (slot / p.npairs) * 8 + xcd;
-    if (split >= p.nsplit) return;                          // whole workgroup leaves together
-    const int npix = p.npix, nhalo = p.IH * p.IW;
-    float* dyl = wl;                                        // [npix][CO_T]
-    float* xl = wl + (size_t)npix * CO_T;                   // [IH*IW][CI_T]
-    int* tab = (int*)(xl + (size_t)nhalo * CI_T);           // [npix] halo offset of tap (0,0)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int col = lane & 31, kk = lane >> 5;
-    const int wco = wave % WCO, wci = (wave / WCO) % WCI, wpx = wave / (WCO * WCI);
-    const int cb = pair / p.ncin, ib = pair % p.ncin;
-    const int co0 = cb * CO_T, ci0 = ib * CI_T;
-    const int nco = min(CO_T, p.Cout - co0), nci = min(CI_T, p.Cin - ci0);
-
-    for (int q = tid; q < npix; q += 256) {
-        const int ty = q / p.TW, tx = q - ty * p.TW;
-        tab[q] = ty < p.TH ? ((ty * ST) * p.IW + tx * ST) * CI_T : 0;
-    }
-    int tapoff[TAPS];
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) tapoff[t] = ((t / KS) * p.IW + (t % KS)) * CI_T;
-
-    f32x16_t acc[NACC];
-#pragma unroll
-    for (int a = 0; a < NACC; ++a)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[a][e] = 0.0f;
-
-    const int steps = npix >> 1;
-    const int s0 = wpx * (steps / WPX), s1 = s0 + steps / WPX;
-    for (int t = split; t < p.ntiles; t += p.nsplit) {
-        const int b = t / (p.tiles_x * p.tiles_y), tt = t % (p.tiles_x * p.tiles_y);
-        const int oy0 = (tt / p.tiles_x) * p.TH, ox0 = (tt % p.tiles_x) * p.TW;
-        __syncthreads();
-        for (int i = tid; i < npix * PCO; i += 256) {
-            const int pix = i / PCO, part = i % PCO;
-            const int ty = pix / p.TW, tx = pix - ty * p.TW;
-            const int oy = oy0 + ty, ox = ox0 + tx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ty < p.TH && oy < p.Ho && ox < p.Wo && part * 4 < nco) {
-                const float* s = (const float*)p.dy + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0 + part * 4;
-                if (part * 4 + 4 <= nco) v = *(const float4*)s;
-                else { v.x = s[0]; if (part * 4 + 1 < nco) v.y = s[1]; if (part * 4 + 2 < nco) v.z = s[2]; }
-            }
-            *(float4*)(dyl + pix * CO_T + part * 4) = v;
-        }
-        const int iy0 = oy0 * ST - PAD, ix0 = ox0 * ST - PAD;
-        for (int i = tid; i < nhalo * PCI; i += 256) {
-            const int pix = i / PCI, part = i % PCI;
-            const int hy = pix / p.IW;
-            const int gy = iy0 + hy, gx = ix0 + pix - hy * p.IW;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && part * 4 < nci) {
-                const float* s = (const float*)p.x + (((size_t)b * p.H + gy) * p.W + gx) * p.x_ld + ci0 + part * 4;
-                if (part * 4 + 4 <= nci) v = *(const float4*)s;
-                else { v.x = s[0]; if (part * 4 + 1 < nci) v.y = s[1]; if (part * 4 + 2 < nci) v.z = s[2]; }
-            }
-            *(float4*)(xl + pix * CI_T + part * 4) = v;
-        }
-        __syncthreads();
-#pragma unroll 2
-        for (int s = s0; s < s1; ++s) {
-            const int q = 2 * s + kk;
-            const float* ap = dyl + q * CO_T + wco * R * 32 + col;
-            const float* bp = xl + tab[q] + wci * R * 32 + col;
-            float a[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) a[r] = ap[r * 32];
-#pragma unroll
-            for (int tp = 0; tp < TAPS; ++tp)
-#pragma unroll
-                for (int rc = 0; rc < R; ++rc) {
-                    const float bv = bp[tapoff[tp] + rc * 32];
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        acc[(tp * R + r) * R + rc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], bv, acc[(tp * R + r) * R + rc], 0, 0, 0);
-                }
-        }
-    }
-    // D[row = co][col = ci]: lane holds col = lane&31, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
-    float* out = p.part + ((size_t)split * WPX + wpx) * p.slice;    // one slice per pixel group
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int rc = 0; rc < R; ++rc) {
-            const int ci = ci0 + (wci * R + rc) * 32 + col;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int co = co0 + (wco * R + r) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-                if (co < p.Cout && ci < p.Cin) {
-                    float* o = out + ((size_t)co * p.Cin + ci) * TAPS;
-#pragma unroll
-                    for (int tp = 0; tp < TAPS; ++tp) o[tp] = acc[(tp * R + r) * R + rc][e];
-                }
-            }
-        }
-}
-
-// Same GEMM on v_mfma_f32_32x32x16_bf16 for bf16 activations / gradients (float32 accumulation and
-// float32 dW).  The MFMA wants, per lane, 8 consecutive K (= pixel) values of one channel, while the
+// The GEMM runs on v_mfma_f32_32x32x16_bf16 (float32 accumulation and float32 dW).  The MFMA wants, per lane, 8 consecutive K (= pixel) values of one channel, while the
 // staged NHWC patches keep channels contiguous: a lane gathers its 8 pixels with eight 16-bit LDS
 // reads (32 consecutive channels per half wave: conflict free), so no transposed copy and no
 // alignment constraint on the tap shifts.  One K step covers 16 pixels of the patch.
@@ -564,20 +458,40 @@ __device__ __forceinline__ uint4 mask_bf16x8(uint4 v, int valid) {   // keep the
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <int KS, int ST, int WCO, int WCI, int R>
+// float4 -> four (hi, lo) bf16 pairs: hi = bf16(v), lo = bf16(v - hi)
+__device__ __forceinline__ void split_store(float4 v, uint16_t* hi, uint16_t* lo) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    uint16_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = f32_to_bf16(f[e]);
+        l[e] = f32_to_bf16(f[e] - bf16_to_f32(h[e]));
+    }
+    *(uint2*)hi = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    *(uint2*)lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+}
+
+// SPLIT: x and dy are float32; every value is staged as two bf16 numbers hi = bf16(v), lo = bf16(v - hi)
+// and a product is taken as hi*hi + hi*lo + lo*hi on three bf16 MFMAs with float32 accumulation (the
+// dropped lo*lo term and the rounding of lo are ~2^-17 of the product): float32-grade weight gradients
+// at five times the rate of the float32 MFMA.
+template <int KS, int ST, int WCO, int WCI, int R, bool SPLIT>
 __global__ void __launch_bounds__(256) conv_wgrad_bf16_kernel(WgradP p) {
     constexpr int TAPS = KS * KS, PAD = (KS - 1) / 2;
     constexpr int CO_T = 32 * WCO * R, CI_T = 32 * WCI * R, WPX = 4 / (WCO * WCI);
     constexpr int NACC = TAPS * R * R;
-    constexpr int PCO = CO_T / 8, PCI = CI_T / 8;          // 16-byte pieces per staged pixel
+    constexpr int EPP = SPLIT ? 4 : 8;                     // elements per 16-byte piece in global memory
+    constexpr int PCO = CO_T / EPP, PCI = CI_T / EPP;      // pieces per staged pixel
     extern __shared__ __attribute__((aligned(16))) char wl8[];
     const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
     const int pair = slot % p.npairs, split = (slot / p.npairs) * 8 + xcd;
     if (split >= p.nsplit) return;
     const int npix = p.npix, nhalo = p.IH * p.IW;
     int* tab = (int*)wl8;                                   // [npix] halo element offset of tap (0,0)
-    uint16_t* dyl = (uint16_t*)(wl8 + (size_t)npix * 4);    // [npix][CO_T]
-    uint16_t* xl = dyl + (size_t)npix * CO_T;               // [IH*IW][CI_T]
+    uint16_t* dyl = (uint16_t*)(wl8 + (size_t)npix * 4);    // [npix][CO_T]   (SPLIT: hi parts)
+    uint16_t* xl = dyl + (size_t)npix * CO_T;               // [IH*IW][CI_T]  (SPLIT: hi parts)
+    uint16_t* dyl_lo = xl + (size_t)nhalo * CI_T;           // SPLIT only: lo parts, same shapes
+    uint16_t* xl_lo = dyl_lo + (size_t)npix * CO_T;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, kk = lane >> 5;
     const int wco = wave % WCO, wci = (wave / WCO) % WCI, wpx = wave / (WCO * WCI);
@@ -611,24 +525,46 @@ __global__ void __launch_bounds__(256) conv_wgrad_bf16_kernel(WgradP p) {
             const int pix = i / PCO, part = i % PCO;
             const int ty = pix / p.TW, tx = pix - ty * p.TW;
             const int oy = oy0 + ty, ox = ox0 + tx;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (ty < p.TH && oy < p.Ho && ox < p.Wo && part * 8 < nco) {
-                v = *(const uint4*)(dyg + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0 + part * 8);
-                if (part * 8 + 8 > nco) v = mask_bf16x8(v, nco - part * 8);
+            const bool in = ty < p.TH && oy < p.Ho && ox < p.Wo && part * EPP < nco;
+            if constexpr (SPLIT) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (in) {
+                    const float* sp = (const float*)p.dy + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0 + part * 4;
+                    if (part * 4 + 4 <= nco) v = *(const float4*)sp;
+                    else { v.x = sp[0]; if (part * 4 + 1 < nco) v.y = sp[1]; if (part * 4 + 2 < nco) v.z = sp[2]; }
+                }
+                split_store(v, dyl + pix * CO_T + part * 4, dyl_lo + pix * CO_T + part * 4);
+            } else {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (in) {
+                    v = *(const uint4*)(dyg + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0 + part * 8);
+                    if (part * 8 + 8 > nco) v = mask_bf16x8(v, nco - part * 8);
+                }
+                *(uint4*)(dyl + pix * CO_T + part * 8) = v;
             }
-            *(uint4*)(dyl + pix * CO_T + part * 8) = v;
         }
         const int iy0 = oy0 * ST - PAD, ix0 = ox0 * ST - PAD;
         for (int i = tid; i < nhalo * PCI; i += 256) {
             const int pix = i / PCI, part = i % PCI;
             const int hy = pix / p.IW;
             const int gy = iy0 + hy, gx = ix0 + pix - hy * p.IW;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && part * 8 < nci) {
-                v = *(const uint4*)(xg + (((size_t)b * p.H + gy) * p.W + gx) * p.x_ld + ci0 + part * 8);
-                if (part * 8 + 8 > nci) v = mask_bf16x8(v, nci - part * 8);
+            const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && part * EPP < nci;
+            if constexpr (SPLIT) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (in) {
+                    const float* sp = (const float*)p.x + (((size_t)b * p.H + gy) * p.W + gx) * p.x_ld + ci0 + part * 4;
+                    if (part * 4 + 4 <= nci) v = *(const float4*)sp;
+                    else { v.x = sp[0]; if (part * 4 + 1 < nci) v.y = sp[1]; if (part * 4 + 2 < nci) v.z = sp[2]; }
+                }
+                split_store(v, xl + pix * CI_T + part * 4, xl_lo + pix * CI_T + part * 4);
+            } else {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (in) {
+                    v = *(const uint4*)(xg + (((size_t)b * p.H + gy) * p.W + gx) * p.x_ld + ci0 + part * 8);
+                    if (part * 8 + 8 > nci) v = mask_bf16x8(v, nci - part * 8);
+                }
+                *(uint4*)(xl + pix * CI_T + part * 8) = v;
             }
-            *(uint4*)(xl + pix * CI_T + part * 8) = v;
         }
         __syncthreads();
         for (int s = s0; s < s1; ++s) {
@@ -637,22 +573,33 @@ __global__ void __launch_bounds__(256) conv_wgrad_bf16_kernel(WgradP p) {
             const int xo[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
             const uint16_t* ap = dyl + q0 * CO_T + wco * R * 32 + col;
             const uint16_t* bp = xl + wci * R * 32 + col;
-            bf16x8_t a[R];
+            bf16x8_t a[R], al[SPLIT ? R : 1];
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[r][e] = (short)ap[e * CO_T + r * 32];
+                for (int e = 0; e < 8; ++e) {
+                    a[r][e] = (short)ap[e * CO_T + r * 32];
+                    if constexpr (SPLIT) al[r][e] = (short)(ap + (dyl_lo - dyl))[e * CO_T + r * 32];
+                }
 #pragma unroll
             for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
                 for (int rc = 0; rc < R; ++rc) {
-                    bf16x8_t bv;
+                    bf16x8_t bv, bl;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) bv[e] = (short)bp[xo[e] + tapoff[tp] + rc * 32];
+                    for (int e = 0; e < 8; ++e) {
+                        bv[e] = (short)bp[xo[e] + tapoff[tp] + rc * 32];
+                        if constexpr (SPLIT) bl[e] = (short)(bp + (xl_lo - xl))[xo[e] + tapoff[tp] + rc * 32];
+                    }
 #pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        acc[(tp * R + r) * R + rc] =
-                            __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r], bv, acc[(tp * R + r) * R + rc], 0, 0, 0);
+                    for (int r = 0; r < R; ++r) {
+                        f32x16_t& c = acc[(tp * R + r) * R + rc];
+                        if constexpr (SPLIT) {
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[r], bv, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r], bl, c, 0, 0, 0);
+                        }
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r], bv, c, 0, 0, 0);
+                    }
                 }
         }
     }
@@ -1083,7 +1030,7 @@ int wgrad_plan(int batch, int h, int w, int cin, int cout, int ksize, int stride
     // patch height: as many rows as keep the staging under 64 KB (two workgroups per CU), at most 128
     // pixels (float32) or 256 (bf16); the pixel count is padded to whole K steps for every pixel group
     const int es = dtype == ODAMD_DTYPE_F32 ? 4 : 2;
-    const int round = dtype == ODAMD_DTYPE_F32 ? 8 : 64, maxpix = dtype == ODAMD_DTYPE_F32 ? 128 : 256;
+    const int round = o.first && dtype == ODAMD_DTYPE_F32 ? 8 : 64, maxpix = dtype == ODAMD_DTYPE_F32 ? 128 : 256;
     for (p.TH = (maxpix / p.TW > 1 ? maxpix / p.TW : 1);; --p.TH) {
         if (p.TH > p.Ho) continue;
         p.npix = (p.TH * p.TW + round - 1) / round * round;
@@ -1113,7 +1060,7 @@ void wgrad_launch(const WgradPlan& o, hipStream_t st) {
     const int key = o.wco * 100 + o.wci * 10 + o.r;
 #define ODAMD_WG(WCO, WCI, R)                                                                                     \
     case WCO * 100 + WCI * 10 + R: {                                                                              \
-        auto k = DT == ODAMD_DTYPE_F32 ? conv_wgrad_f32_kernel<KS, ST, WCO, WCI, R> : conv_wgrad_bf16_kernel<KS, ST, WCO, WCI, R>; \
+        auto k = conv_wgrad_bf16_kernel<KS, ST, WCO, WCI, R, DT == ODAMD_DTYPE_F32>;                               \
         if (o.lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o.lds); \
         k<<<o.grid, 256, o.lds, st>>>(o.p);                                                                       \
         break;                                                                                                    \
