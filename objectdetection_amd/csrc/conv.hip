@@ -853,13 +853,16 @@ TileChoice choose_tile(int Ho, int Wo, int npix, int ks, int st, int ps, size_t 
         int th = npix / tw;
         if (th > Ho) th = Ho;
         if (even) { if ((tw & 1) || th < 2) continue; th &= ~1; }
-        if (th < 1) continue;
-        const int ih = (th - 1) * st + ks, iw = (tw - 1) * st + ks;
-        if (ih * iw > max_pix) continue;
-        if ((((size_t)ih * iw * ps + 255) & ~(size_t)255) + w_bytes > (size_t)LDS_LIMIT) continue;
-        const double tiles = (double)((Wo + tw - 1) / tw) * ((Ho + th - 1) / th);
-        const double cost = tiles * (ih * iw + 0.25 * npix);  // staged pixels + a share for idle lanes
-        if (cost < best_cost) { best_cost = cost; best = {th, tw, ih, iw, true}; }
+        // the tallest patch of this width whose halo and weight slab fit
+        for (; th >= (even ? 2 : 1); th -= (even ? 2 : 1)) {
+            const int ih = (th - 1) * st + ks, iw = (tw - 1) * st + ks;
+            if (ih * iw > max_pix) continue;
+            if ((((size_t)ih * iw * ps + 255) & ~(size_t)255) + w_bytes > (size_t)LDS_LIMIT) continue;
+            const double tiles = (double)((Wo + tw - 1) / tw) * ((Ho + th - 1) / th);
+            const double cost = tiles * (ih * iw + 0.25 * npix);  // staged pixels + a share for idle lanes
+            if (cost < best_cost) { best_cost = cost; best = {th, tw, ih, iw, true}; }
+            break;
+        }
     }
     return best;
 }

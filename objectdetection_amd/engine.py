@@ -341,7 +341,7 @@ class Plan:
         self.refresh_weights()
         st = _stream()
         img = image.data_ptr()
-        for fn, args, name, image_slot in self.launches:
+        for i, (fn, args, name, image_slot) in enumerate(self.launches):
             if name == 'copy':
                 x, y = args
                 self.bufs[y.buf][..., y.c0:y.c0 + x.cphys].copy_(self.bufs[x.buf][..., x.c0:x.c0 + x.cphys])
@@ -350,7 +350,8 @@ class Plan:
                 args[image_slot] = img
             rc = fn(*args, st)
             if rc:
-                check(rc, name)
+                m = self.meta.get(i, {})
+                check(rc, f"{name} #{i} {m.get('kernel', '')} {m.get('shape', '')}")
         return self.finish(self, image) if self.finish else self.outputs.get('nchw')
 
     def profile(self, image, repeats=3):
