@@ -317,9 +317,34 @@ def gen_training():
     save('training.npz', **out)
 
 
+def gen_pruned():
+    """yolov7(args, config=...) as the pruning step of train_class.py:367-386 rebuilds it: irregular cbs
+    widths.  Stores the width list, every state_dict key with its shape, and the eval output."""
+    args = patterns.default_args(input_size=64, output_class=3)
+    std = ref_yolov7(args)
+    widths = [m.conv.out_channels for m in std.modules() if isinstance(m, ref_layer.cbs)]
+    cfg = [max(5, w - w // 5 - (i % 3)) for i, w in enumerate(widths)]
+    net = ref_yolov7(args, config=cfg)
+    patterns.fill_state_dict(net)
+    net.eval()
+    x = patterns.image_batch(2, 64)
+    with torch.no_grad():
+        y = net(x).numpy()
+    sd = net.state_dict()
+    keys = list(sd.keys())
+    shapes = np.zeros((len(keys), 4), np.int64)
+    for i, k in enumerate(keys):
+        shp = tuple(sd[k].shape)
+        shapes[i, :len(shp)] = shp
+    save('pruned.npz', widths=np.asarray(widths), cfg=np.asarray(cfg), keys=np.asarray(keys), shapes=shapes, eval=y)
+
+
 if __name__ == '__main__':
     if len(_ARGV) > 1 and _ARGV[1] == 'net128':
         gen_net128()
+        sys.exit(0)
+    if len(_ARGV) > 1 and _ARGV[1] == 'pruned':
+        gen_pruned()
         sys.exit(0)
     gen_blocks()
     gen_net128()
@@ -327,3 +352,4 @@ if __name__ == '__main__':
     gen_decode()
     gen_nms()
     gen_training()
+    gen_pruned()

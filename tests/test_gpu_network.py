@@ -218,3 +218,65 @@ def test_every_layer_against_oracle_taps(od, dtype, preset, size):
             assert err < TOL[dtype], (names[m], err)
             checked += 1
     assert checked >= {'s': 55, 'm': 60, 'l': 70}[preset], checked
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_pruned_config_network(od, dtype):
+    """A pruned network (train_class.py:367-386 rebuilds yolov7 from a list of irregular cbs widths):
+    every layer against the oracle.  Irregular widths exercise the zero-padded channel slices."""
+    engine, layer, ymod = od
+    args = patterns.default_args(input_size=64, output_class=3)
+    torch.manual_seed(31)
+    std = ymod.yolov7(args)
+    widths = [m.conv.out_channels for m in std.modules() if isinstance(m, layer.cbs)]
+    cfg = [max(5, w - w // 5 - (i % 3)) for i, w in enumerate(widths)]
+    net = ymod.yolov7(args, config=cfg)
+    got_widths = [m.conv.out_channels for m in net.modules() if isinstance(m, layer.cbs)]
+    assert got_widths == cfg
+    g = torch.Generator().manual_seed(32)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.bias.shape, generator=g) * 0.5 + 0.25)
+    x = torch.rand(2, 3, 64, 64, generator=g)
+    taps = {}
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        ref = network.yolov7_forward(sd, x, args, taps=taps).numpy()
+    net = net.cuda().eval()
+    names = {m: n for n, m in net.named_modules()}
+    engine.set_compute_dtype(dtype)
+    try:
+        got = net(x.cuda()).cpu().numpy()
+        plan = net._plan(x.cuda())
+    finally:
+        engine.set_compute_dtype(None)
+    assert rel_err(got[..., :4], ref[..., :4]) < TOL[dtype]
+    assert rel_err(got[..., 4:], ref[..., 4:]) < TOL[dtype]
+    checked = 0
+    for op in plan.b.ops:
+        if op['kind'] not in ('conv', 'first'):
+            continue
+        y = op['y']
+        buf = plan.bufs[y.buf][..., y.c0:y.c0 + y.cphys].float().cpu()
+        mods = op.get('mods', [op['mod']])
+        if len(mods) > 1 or len(y.segments) > 1:
+            continue
+        r = taps[names[mods[0]]].permute(0, 2, 3, 1)
+        assert rel_err(buf[..., :r.shape[3]].numpy(), r.numpy()) < TOL[dtype], names[mods[0]]
+        checked += 1
+    assert checked >= 50
+
+
+def test_pruned_network_vs_reference_fixture(od, golden):
+    engine, layer, ymod = od
+    g = golden('pruned.npz')
+    args = patterns.default_args(input_size=64, output_class=3)
+    net = ymod.yolov7(args, config=g['cfg'].tolist())
+    patterns.fill_state_dict(net)
+    got = net.cuda().eval()(patterns.image_batch(2, 64).cuda()).cpu().numpy()
+    assert rel_err(got[..., :4], g['eval'][..., :4]) < TOL['f32']
+    assert rel_err(got[..., 4:], g['eval'][..., 4:]) < TOL['f32']
