@@ -377,6 +377,14 @@ constexpr int MASK_WAVES = 4;
 __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// w = 2*w + bit(lane) with the bit taken from a lane mask: one v_addc_co_u32 (carry-in = the mask).
+__device__ __forceinline__ uint32_t shift_in(uint32_t w, u64 lane_mask) {
+    uint32_t r;
+    u64 carry_out;
+    asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(w), "s"(lane_mask));
+    return r;
+}
+
 // Per-box values derived once: corners, area and whether the cheap overlap test is valid for it.
 struct BoxEx { float x2, y2, area, special; };
 __device__ __forceinline__ BoxEx box_ex(const float4 c) {
@@ -386,7 +394,7 @@ __device__ __forceinline__ BoxEx box_ex(const float4 c) {
     e.area = c.z * c.w;
     // "regular" box: positive extent that survives rounding, positive finite area.  For two
     // regular boxes without overlap the reference arithmetic gives inter = +0, union > 0, IoU = +0.
-    const bool regular = (e.x2 > c.x) && (e.y2 > c.y) && (e.area > 0.0f) && (e.area < 3.0e38f) &&
+    const bool regular = (e.x2 > c.x) && (e.y2 > c.y) && (e.area > 1.0e-30f) && (e.area < 3.0e38f) &&
                          (fabsf(c.x) < 3.0e38f) && (fabsf(c.y) < 3.0e38f) && (e.x2 < 3.0e38f) && (e.y2 < 3.0e38f);
     e.special = regular ? 0.0f : 1.0f;
     return e;
@@ -415,6 +423,10 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
                 int n_pad, int row_begin, int row_end, float thr, u64* __restrict__ mask, size_t mask_stride_img) {
     __shared__ float4 cols[MASK_WAVES][64];
     __shared__ float4 colx[MASK_WAVES][64];
+    __shared__ u64 col_special[MASK_WAVES];
+    const bool thr_ok = thr > 1.0e-30f && thr < 1.0e30f;
+    const double t_lo = (double)thr * (1.0 - 3.814697265625e-6), t_hi = (double)thr * (1.0 + 3.814697265625e-6);
+    const float k_lo = (float)(t_lo / (1.0 + t_lo)), k_hi = (float)(t_hi / (1.0 + t_hi));
     const int b = blockIdx.z;
     const int n = count ? min(count[b], n_pad) : n_pad;
     const int words = n_pad >> 6;
@@ -432,7 +444,10 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
         const float4 c = (ct * 64 + lane < n) ? boxes[ct * 64 + lane] : make_float4(0, 0, 0, 0);
         const BoxEx e = box_ex(c);
         cols[wave][lane] = c;
-        colx[wave][lane] = make_float4(e.x2, e.y2, e.area, e.special);
+        // the column's share of the two decision thresholds (see below): k * area
+        colx[wave][lane] = make_float4(e.x2, e.y2, k_lo * e.area, k_hi * e.area);
+        const u64 sp = __ballot(e.special != 0.0f);
+        if (lane == 0) col_special[wave] = sp;
     }
     __syncthreads();
     if (!active) continue;
@@ -444,34 +459,45 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
     if (live_mask) {
         const float4 a = live ? boxes[i] : make_float4(0, 0, 0, 0);
         const BoxEx ae = box_ex(a);
-        const bool a_special = ae.special != 0.0f;
-        // Division-free decision with a guard band: for regular boxes
-        //   inter < union*thr*(1-2^-20)  =>  fl(inter/union) <  thr   (survives)
-        //   inter > union*thr*(1+2^-20)  =>  fl(inter/union) >= thr   (suppressed)
-        // (the band is 2^4 times wider than all roundings involved); anything else -- a pair inside
-        // the band, an irregular box, a tiny union, thr <= 0 -- takes the exact reference arithmetic.
-        const bool thr_ok = thr > 1.0e-30f && thr < 1.0e30f;
-        const float thr_lo = thr * (1.0f - 9.5367431640625e-7f), thr_hi = thr * (1.0f + 9.5367431640625e-7f);
-        uint32_t lo = 0, hi = 0;
+        // Division-free decision with a guard band.  For regular boxes (positive extents, area between
+        // 1e-30 and 3e38) IoU >= thr is inter * (1 + thr) >= thr * (areaA + areaC); with
+        // k_lo = t/(1+t) at t = thr*(1 - 2^-18) and k_hi likewise at thr*(1 + 2^-18):
+        //   inter < k_lo*areaA + k_lo*areaC  =>  fl(inter/union) <  thr   (survives)
+        //   inter > k_hi*areaA + k_hi*areaC  =>  fl(inter/union) >= thr   (suppressed)
+        // (the band is an order of magnitude wider than the ~10 roundings involved); a pair inside the
+        // band, an irregular box or an unusable threshold takes the exact reference arithmetic.
+        const float a_lo = k_lo * ae.area, a_hi = k_hi * ae.area;
+        const u64 row_special = __ballot(ae.special != 0.0f || !live) | (thr_ok ? 0ull : ~0ull);
+        const u64 cs_ = col_special[wave];            // same for the whole wave: keep it in scalar registers
+        const u64 cspec = ((u64)__builtin_amdgcn_readfirstlane((uint32_t)(cs_ >> 32)) << 32) |
+                          __builtin_amdgcn_readfirstlane((uint32_t)cs_);
+        uint32_t half[2] = {0u, 0u};
+#pragma unroll
+        for (int hh = 1; hh >= 0; --hh) {
+            uint32_t w32 = 0;
 #pragma unroll 8
-        for (int j = 0; j < 64; ++j) {
-            const float4 c = cols[wave][j];
-            const float4 e = colx[wave][j];
-            const float x1 = vmax(a.x, c.x), y1 = vmax(a.y, c.y);
-            const float x2 = vmin(ae.x2, e.x), y2 = vmin(ae.y2, e.y);
-            const float inter = vmax(x2 - x1, 0.0f) * vmax(y2 - y1, 0.0f);
-            const float uni = ae.area + e.z - inter;
-            const bool big = uni > 1.0e-30f;
-            const bool keep_sure = (inter < uni * thr_lo) && big;
-            bool sup = (inter > uni * thr_hi) && big;
-            const bool amb = !(keep_sure || sup) || a_special || (e.w != 0.0f) || !thr_ok;
-            if (__ballot(amb && live)) {
-                if (amb) sup = suppresses(a, c, thr);
+            for (int jj = 31; jj >= 0; --jj) {      // descending: the shift-in below builds bit jj last-in-lowest
+                const int j = hh * 32 + jj;
+                const float4 c = cols[wave][j];
+                const float4 e = colx[wave][j];
+                const float x1 = vmax(a.x, c.x), y1 = vmax(a.y, c.y);
+                const float x2 = vmin(ae.x2, e.x), y2 = vmin(ae.y2, e.y);
+                const float inter = vmax(x2 - x1, 0.0f) * vmax(y2 - y1, 0.0f);
+                const u64 keep_sure = __ballot(inter < a_lo + e.z);
+                u64 sup = __ballot(inter > a_hi + e.w);
+                // lanes that need the exact arithmetic: undecided, irregular row box, or the whole
+                // column when its box is irregular
+                u64 amb = (~(keep_sure | sup) | row_special | (((cspec >> j) & 1ull) ? ~0ull : 0ull)) & live_mask;
+                if (amb) {
+                    const bool mine = (amb >> lane) & 1ull;
+                    const u64 exact = __ballot(mine && suppresses(a, c, thr));
+                    sup = (sup & ~amb) | exact;
+                }
+                w32 = shift_in(w32, sup);
             }
-            if (j < 32) lo |= sup ? (1u << j) : 0u;
-            else hi |= sup ? (1u << (j - 32)) : 0u;
+            half[hh] = w32;
         }
-        word = ((u64)hi << 32) | lo;
+        word = ((u64)half[1] << 32) | half[0];
         const int ncol = n - ct * 64;                                     // valid columns of this tile
         if (ncol < 64) word &= (1ull << ncol) - 1ull;
         if (ct == rt) word &= lane == 63 ? 0ull : ~((2ull << lane) - 1ull);  // strictly later boxes only
