@@ -539,6 +539,13 @@ nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int*
         const int i = t_begin * 64 + lane;
         diag_next = (i < n) ? m[(size_t)(i - row_begin) * words + t_begin] : 0ull;
     }
+    const int w0 = threadIdx.x;
+    u64 v[64];
+    if (w0 > t_begin && w0 < nwords) {
+        const u64* m0 = m + (size_t)(t_begin * 64 - row_begin) * words;
+#pragma unroll
+        for (int u = 0; u < 64; ++u) v[u] = m0[(size_t)u * words + w0];
+    }
     for (int t = t_begin; t < t_end; ++t) {
         if (threadIdx.x < 64) {
             const int i = t * 64 + lane;
@@ -577,19 +584,33 @@ nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int*
         __syncthreads();
         const u64 kept = kept_bits;
         const u64* mt = m + (size_t)(t * 64 - row_begin) * words;
-        for (int w = t + 1 + threadIdx.x; w < nwords; w += SCAN_THREADS) {
-            // all 64 row words in flight at once (two batches of 32); rows that were not kept are
-            // loaded too and masked out, which keeps the loads free of branches
+        // column word w0 = threadIdx.x: its 64 row words of this tile were loaded before the tile was
+        // resolved (the loads do not depend on the outcome: rows that were not kept are masked out)
+        if (w0 > t && w0 < nwords) {
+            u64 acc = 0;
+#pragma unroll
+            for (int u = 0; u < 64; ++u) acc |= ((kept >> u) & 1ull) ? v[u] : 0ull;
+            removed[w0] |= acc;
+        }
+        // further column words (more than 16384 candidates): loaded here, two batches of 32
+        for (int w = w0 + SCAN_THREADS; w < nwords; w += SCAN_THREADS) {
+            if (w <= t) continue;
             u64 acc = 0;
 #pragma unroll
             for (int q0 = 0; q0 < 64; q0 += 32) {
-                u64 v[32];
+                u64 x[32];
 #pragma unroll
-                for (int u = 0; u < 32; ++u) v[u] = mt[(size_t)(q0 + u) * words + w];
+                for (int u = 0; u < 32; ++u) x[u] = mt[(size_t)(q0 + u) * words + w];
 #pragma unroll
-                for (int u = 0; u < 32; ++u) acc |= ((kept >> (q0 + u)) & 1ull) ? v[u] : 0ull;
+                for (int u = 0; u < 32; ++u) acc |= ((kept >> (q0 + u)) & 1ull) ? x[u] : 0ull;
             }
             removed[w] |= acc;
+        }
+        // the next tile's rows: in flight while that tile is being resolved
+        if (t + 1 < t_end && w0 > t + 1 && w0 < nwords) {
+            const u64* mn = mt + (size_t)64 * words;
+#pragma unroll
+            for (int u = 0; u < 64; ++u) v[u] = mn[(size_t)u * words + w0];
         }
         __syncthreads();
     }
