@@ -439,7 +439,8 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
     for (int grp = rt / MASK_WAVES + blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int ct = grp * MASK_WAVES + wave;  // global column tile
     const bool active = (ct >= rt) && (ct < nwords);
-    __syncthreads();                         // previous iteration's LDS reads are done
+    // every wave stages and reads only its own LDS slice: a wave-level barrier orders its accesses
+    __builtin_amdgcn_wave_barrier();
     if (active) {
         const float4 c = (ct * 64 + lane < n) ? boxes[ct * 64 + lane] : make_float4(0, 0, 0, 0);
         const BoxEx e = box_ex(c);
@@ -449,7 +450,7 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
         const u64 sp = __ballot(e.special != 0.0f);
         if (lane == 0) col_special[wave] = sp;
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     if (!active) continue;
     const int i = rt * 64 + lane;
     u64 word = 0;
