@@ -235,6 +235,13 @@ int odamd_detection_loss_dev(const float* pred, float* dpred, const int* screen,
                              const float* label, int batch, int rows, int kdim, const int* n_pos_dev, int capacity,
                              float label_smooth, float* out4, void* workspace, size_t workspace_bytes, void* stream);
 
+/* predict_class._image_process (predict.py:60-65): (h, w, 3) uint8 image on the device ->
+ * cv2.resize(image, (size, size)) [8-bit bilinear, OpenCV's fixed-point scheme] -> / 255 -> (1, 3, size, size)
+ * float32.  The scheme is restated from OpenCV's documentation and source, which is not available in
+ * the build environment: parity with cv2 is unpinned (the test pins it against a numpy restatement and
+ * against exact bilinear interpolation within one grey level). */
+int odamd_preprocess_u8(const uint8_t* image_hwc, int h, int w, float* out_chw, int size, void* stream);
+
 /* torch_dataset label -> grid-row assignment (train_class.py:537-543 ranges = decode(-4) .. decode(+4) of
  * every grid row, :578-607 strict containment of the label's cx, cy, w, h) for a whole batch on the
  * device.  geometry: grid sizes, strides and anchors as for odamd_decode (head pointers ignored, kdim =

@@ -95,6 +95,49 @@ __global__ void __launch_bounds__(256) decode_bwd_kernel(DecodeGeom g, const flo
 }
 
 // ------------------------------------------------------------------------------------------
+// predict_class._image_process (predict.py:60-65): cv2.resize(image, (S, S)) [bilinear] -> float / 255
+// -> (1, 3, S, S).  The resize follows OpenCV's 8-bit INTER_LINEAR scheme: source position
+// (d + 0.5) * scale - 0.5, clamped taps, weights rounded to 11 fractional bits, horizontal pass in
+// integers, vertical pass ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2, result a byte.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void resize_tap(int d, float scale, int n_src, int* s0, int* s1, int* w0, int* w1) {
+    float f = ((float)d + 0.5f) * scale - 0.5f;
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { s = 0; f = 0.0f; }
+    if (s >= n_src - 1) { s = n_src - 1; f = 0.0f; }
+    *s0 = s;
+    *s1 = s + 1 < n_src ? s + 1 : s;
+    *w0 = (int)rintf((1.0f - f) * 2048.0f);
+    *w1 = (int)rintf(f * 2048.0f);
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_u8_kernel(const uint8_t* __restrict__ img, int H0, int W0, float* __restrict__ out, int S) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S * S) return;
+    const int dy = i / S, dx = i - dy * S;
+    int x0, x1, a0, a1, y0, y1, b0, b1;
+    if (W0 == S) { x0 = x1 = dx; a0 = 2048; a1 = 0; } else resize_tap(dx, (float)W0 / (float)S, W0, &x0, &x1, &a0, &a1);
+    if (H0 == S) { y0 = y1 = dy; b0 = 2048; b1 = 0; } else resize_tap(dy, (float)H0 / (float)S, H0, &y0, &y1, &b0, &b1);
+    const uint8_t* r0 = img + (size_t)y0 * W0 * 3;
+    const uint8_t* r1 = img + (size_t)y1 * W0 * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int v;
+        if (W0 == S && H0 == S) {
+            v = r0[x0 * 3 + c];
+        } else {
+            const int h0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+            const int h1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+            v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        out[(size_t)c * S * S + i] = (float)v / 255.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Label -> grid-row assignment of torch_dataset (train_class.py:537-543, :578-607) for a batch.
 // A grid row can express boxes between decode(-4) and decode(+4) of its cell and anchor; a label
 // is assigned to every row whose range strictly contains its (cx, cy, w, h).  The reference's
@@ -831,6 +874,12 @@ int odamd_decode(const odamd_decode_desc* d, float* out, void* stream) {
     int gx = (maxn + 255) / 256;
     if (gx > 2048) gx = 2048;
     decode_kernel<<<dim3(gx, 3, d->batch), 256, 0, (hipStream_t)stream>>>(g, out);
+    return (int)hipGetLastError();
+}
+
+int odamd_preprocess_u8(const uint8_t* image_hwc, int h, int w, float* out_chw, int size, void* stream) {
+    if (!image_hwc || !out_chw || h < 1 || w < 1 || size < 1 || h > 32768 || w > 32768) return ODAMD_E_ARG;
+    preprocess_u8_kernel<<<(size * size + 255) / 256, 256, 0, (hipStream_t)stream>>>(image_hwc, h, w, out_chw, size);
     return (int)hipGetLastError();
 }
 

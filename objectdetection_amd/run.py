@@ -46,6 +46,15 @@ def build_parser():
     p.add_argument('--local_rank', '--local-rank', default=int(os.environ.get('LOCAL_RANK', 0)), type=int)
     p.add_argument('--label_smooth', default=0.01, type=float)
     p.add_argument('--synthetic_images', default=512, type=int)
+    # flags of the reference kept for command-line compatibility
+    p.add_argument('--amp', default=False, type=_bool, help='mixed precision: the bf16 training step (run.py:47)')
+    p.add_argument('--latch', default=True, type=_bool)
+    p.add_argument('--noise', default=0.5, type=float)
+    p.add_argument('--save_best', default='best.pt', type=str)
+    p.add_argument('--prune_weight_path', default='prune_source.pt', type=str)
+    p.add_argument('--prune_ratio', default=0.8, type=float)
+    p.add_argument('--confidence_threshold', default=0.5, type=float)
+    p.add_argument('--iou_threshold', default=0.5, type=float)
     return p
 
 
@@ -59,12 +68,14 @@ def main(argv=None):
     if args.distributed:
         torch.cuda.set_device(args.local_rank)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group(backend='nccl')
         args.device = torch.device('cuda', args.local_rank)
+        torch.distributed.init_process_group(backend='nccl', device_id=args.device)
     torch.manual_seed(999)
     torch.cuda.manual_seed_all(999)
     from .train_class import train_class
     train_class(args).train()
+    if args.distributed:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

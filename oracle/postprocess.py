@@ -86,3 +86,33 @@ def predict_decode(pred, image_shape, input_size, confidence_threshold, iou_thre
     out[:, 2] *= xs
     out[:, 3] *= ys
     return out, idx[keep]
+
+
+def resize_u8_linear(image, size):
+    """cv2.resize(image, (size, size)) for uint8 images, INTER_LINEAR, restated from OpenCV's fixed-point
+    scheme (predict.py:61 calls it): taps at (d + 0.5) * scale - 0.5, weights rounded to 11 fractional
+    bits, vertical pass (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.
+    Parity with cv2 itself is unpinned: cv2 is not installed where this build runs."""
+    h0, w0 = image.shape[:2]
+    if h0 == size and w0 == size:
+        return image.copy()
+
+    def taps(n_dst, n_src):
+        f = ((np.arange(n_dst, dtype=np.float32) + np.float32(0.5)) * np.float32(n_src / n_dst) - np.float32(0.5)).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        lo, hi = s < 0, s >= n_src - 1
+        s = np.clip(s, 0, n_src - 1)
+        f[lo | hi] = 0
+        s1 = np.minimum(s + 1, n_src - 1)
+        w0_ = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+        w1_ = np.rint(f * np.float32(2048)).astype(np.int64)
+        return s, s1, w0_, w1_
+
+    x0, x1, a0, a1 = taps(size, w0) if w0 != size else (np.arange(size), np.arange(size), np.full(size, 2048), np.zeros(size, np.int64))
+    y0, y1, b0, b1 = taps(size, h0) if h0 != size else (np.arange(size), np.arange(size), np.full(size, 2048), np.zeros(size, np.int64))
+    img = image.astype(np.int64)
+    hz = img[:, x0] * a0[None, :, None] + img[:, x1] * a1[None, :, None]          # (h0, size, 3)
+    r0, r1 = hz[y0], hz[y1]
+    v = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)

@@ -100,3 +100,57 @@ def test_detect_pipeline_matches_sequential():
                 assert torch.equal(rows[b, :n], r.rows.cpu()[b, :n])
     finally:
         engine.set_compute_dtype(None)
+
+
+@pytest.mark.parametrize('h,w,size', [(480, 640, 128), (100, 37, 64), (64, 64, 64), (20, 30, 64), (641, 1283, 640)])
+def test_device_preprocess_matches_restated_cv2_resize(h, w, size):
+    """odamd_preprocess_u8 (resize + /255 + HWC->CHW) equals the numpy restatement of OpenCV's 8-bit
+    bilinear resize exactly, and that restatement stays within one grey level of exact bilinear
+    interpolation (cv2 itself is not installed here: parity with it is unpinned)."""
+    import ctypes as C
+    import torch
+    from objectdetection_amd._lib import lib, check
+    from oracle import postprocess as opost
+    rng = np.random.default_rng(h * 7 + w)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    want = opost.resize_u8_linear(img, size)
+    src = torch.from_numpy(img).cuda()
+    out = torch.empty((1, 3, size, size), dtype=torch.float32, device='cuda')
+    check(lib.odamd_preprocess_u8(src.data_ptr(), h, w, out.data_ptr(), size, None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()[0].transpose(1, 2, 0)
+    np.testing.assert_array_equal(got, want.astype(np.float32) / np.float32(255))
+    # exact bilinear (float64, half-pixel centres, clamped)
+    fy = np.clip((np.arange(size) + 0.5) * h / size - 0.5, 0, h - 1)
+    fx = np.clip((np.arange(size) + 0.5) * w / size - 0.5, 0, w - 1)
+    y0, x0 = np.floor(fy).astype(int), np.floor(fx).astype(int)
+    y1, x1 = np.minimum(y0 + 1, h - 1), np.minimum(x0 + 1, w - 1)
+    wy, wx = (fy - y0)[:, None, None], (fx - x0)[None, :, None]
+    im = img.astype(np.float64)
+    ref = (im[y0][:, x0] * (1 - wy) * (1 - wx) + im[y0][:, x1] * (1 - wy) * wx
+           + im[y1][:, x0] * wy * (1 - wx) + im[y1][:, x1] * wy * wx)
+    assert np.abs(want.astype(np.float64) - ref).max() <= 1.0
+
+
+def test_checkpoint_round_trip_train_to_predict(tmp_path):
+    """run.py-style training writes a checkpoint; predict_class loads it (pickled module, as
+    predict.py:29-30 does) and predicts on an image of another size (device-side resize)."""
+    import argparse
+    import torch
+    from oracle import patterns
+    from objectdetection_amd.train_class import train_class
+    from objectdetection_amd.predict import predict_class
+    path = str(tmp_path / 'last.pt')
+    a = patterns.default_args(input_size=128, output_class=3)
+    a.__dict__.update(device='cuda', batch=4, epoch=1, lr_start=0.001, lr_end_ratio=0.1, lr_end_epoch=10,
+                      warmup_ratio=0.01, regularization='L2', r_value=0.0005, ema=True, distributed=False, local_rank=0,
+                      weight_path='', weight_again=True, print_info=False, synthetic_images=8, save_path=path, save_epoch=1)
+    torch.manual_seed(2)
+    train_class(a).train()
+    pa = argparse.Namespace(device='cuda', float16=True, input_size=128, confidence_threshold=0.3, iou_threshold=0.5)
+    pc = predict_class(path, pa)
+    img = np.random.default_rng(4).integers(0, 256, (300, 400, 3), dtype=np.uint8)
+    out = pc.predict(img)
+    assert out is None or (out.ndim == 2 and out.shape[1] == 8 and np.isfinite(out).all())
+    again = pc.predict(img)
+    assert (out is None) == (again is None) and (out is None or np.array_equal(out, again))
