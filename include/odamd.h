@@ -106,6 +106,32 @@ int odamd_postprocess_heads(const odamd_decode_desc* d, float conf_thr, float io
 int odamd_nms_rows(const float* rows_xywh, int batch, int rows, int kdim, float iou_thr, int n_pad, float* out_rows,
                    int* out_idx, int* out_count, int max_keep, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Candidate selection + NMS of the validation metric (train_class.py:340-346 with :76-83): pred is
+ * the NON-deployed (B,R,K) tensor (cx,cy,w,h,raw conf,raw cls..).  Rows with conf > conf_thr become
+ * (x_min,y_min,w,h) boxes, score = conf * max(cls); greedy NMS in stable descending score order
+ * suppresses a candidate iff IoU > nms_thr (the caller passes 1 - iou_threshold, train_class.py:80;
+ * the rule of torchvision.ops.nms on corner boxes); the first max_keep kept rows (the reference
+ * uses 100, train_class.py:346) are written as (x_min,y_min,w,h,conf,cls..), out_count holds the
+ * uncapped number kept.  Other arguments as in odamd_postprocess. */
+int odamd_metric_nms(const float* pred, int batch, int rows, int kdim, float conf_thr, float nms_thr, int n_pad,
+                     float* out_rows, int* out_idx, int* out_count, int* cand_count, int max_keep, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* Stand-alone train_class.nms (train_class.py:77-83): rows are (x_min,y_min,w,h,conf,cls..), all of
+ * them candidates; same ordering and suppression rule as odamd_metric_nms; kept rows are written
+ * in keep order with w, h as the corner round trip (x_min + w) - x_min leaves them. */
+int odamd_metric_nms_rows(const float* rows_xywh, int batch, int rows, int kdim, float nms_thr, int n_pad,
+                          float* out_rows, int* out_idx, int* out_count, int max_keep, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* True / false positive counting of train_class.metric (train_class.py:347-365) for a batch:
+ * kept_rows (B,max_keep,K) and keep_count (B) as written by odamd_metric_nms (max_keep <= 1024),
+ * labels (B,lmax,K) rows (cx,cy,w,h,conf,cls..) with n_label (B) valid rows per image.  A label is
+ * found when a kept row of the same argmax class has IoU > iou_thr with it (train_class.py:67-74).
+ * counts: (B,3) int32 = (tp, fn, fp) per image. */
+int odamd_metric_match(const float* kept_rows, const int* keep_count, int max_keep, const float* labels,
+                       const int* n_label, int lmax, int batch, int kdim, float iou_thr, int* counts, void* stream);
+
 /* Building blocks of the chain, exported for tests and for callers that bring their own
  * candidate set.  boxes: (n) float4 {x_min,y_min,w,h}; bit j of mask word (i, j/64) is set
  * iff j > i and not (IoU(i,j) < iou_thr).  predict.py:33-41. */

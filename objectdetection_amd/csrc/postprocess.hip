@@ -255,7 +255,12 @@ struct FilterSrc {
 
 // SRC == 0: rows are the deployed (B,R,K) tensor.  SRC == 1: rows are RAW head rows; decode and
 // sigmoid are evaluated per surviving row.  SRC == 2: rows are already (x_min,y_min,w,h,..) and
-// every row is a candidate (the stand-alone _nms of predict.py:82-92).
+// every row is a candidate (the stand-alone _nms of predict.py:82-92).  SRC == 3: the validation
+// metric's candidates (train_class.py:340-342,78): (cx,cy,w,h,..) rows of the NON-deployed tensor,
+// kept when the raw objectness exceeds the threshold, no positivity test; ties in the score go to
+// the lower row (a stable descending sort), so the row is stored complemented in the key.
+// SRC == 4: the same rule on rows that are already (x_min,y_min,w,h,..), every row a candidate
+// (the stand-alone nms of train_class.py:77-83).
 // A workgroup copies `rows_stage` whole rows of one range into LDS with coalesced loads (row
 // stride padded to an odd number of words, so the per-row walk is bank-conflict free); then one
 // lane per row evaluates predict.py:68-70,83: objectness first, so a rejected row costs one exp.
@@ -300,7 +305,7 @@ filter_kernel(FilterSrc fs, DecodeGeom g, int rows, int kdim, int rows_stage, fl
             const float* p = lds + r * ldk;
             float conf = p[4];
             if (SRC == 1) conf = sigmoid_f32(conf);
-            if (SRC == 2 || conf > conf_thr) {
+            if (SRC == 2 || SRC == 4 || conf > conf_thr) {
                 float cx = p[0], cy = p[1], bw = p[2], bh = p[3];
                 if (SRC == 1) {
                     const int lrow = lrow0 + r;
@@ -312,16 +317,20 @@ filter_kernel(FilterSrc fs, DecodeGeom g, int rows, int kdim, int rows_stage, fl
                     bw = decode_value(g, s, 2, a, y, x, bw);
                     bh = decode_value(g, s, 3, a, y, x, bh);
                 }
-                const float xmin = SRC == 2 ? cx : cx - bw / 2.0f;
-                const float ymin = SRC == 2 ? cy : cy - bh / 2.0f;
-                pass = SRC == 2 || ((xmin > 0.0f) && (ymin > 0.0f));
+                const float xmin = (SRC == 2 || SRC == 4) ? cx : cx - bw / 2.0f;
+                const float ymin = (SRC == 2 || SRC == 4) ? cy : cy - bh / 2.0f;
+                pass = SRC >= 2 || ((xmin > 0.0f) && (ymin > 0.0f));
                 if (pass) {
                     // the sigmoid is monotone, so the largest class probability is the sigmoid of the
                     // largest class logit: one exp per surviving row instead of one per class
                     float m = p[5];
                     for (int k = 6; k < kdim; ++k) m = fmaxf(m, p[k]);
                     if (SRC == 1) m = sigmoid_f32(m);
-                    key = make_key(conf * m, row0 + r);
+                    key = make_key(conf * m, SRC >= 3 ? ~(row0 + r) : row0 + r);
+                    if (SRC >= 3) {   // extents as the corner form x_max - x_min carries them (train_class.py:79)
+                        bw = (xmin + bw) - xmin;
+                        bh = (ymin + bh) - ymin;
+                    }
                     rowbox[(size_t)b * rows + row0 + r] = make_float4(xmin, ymin, bw, bh);
                 }
             }
@@ -389,11 +398,12 @@ __global__ void __launch_bounds__(256) bitonic_global_kernel(u64* __restrict__ k
 
 __global__ void __launch_bounds__(256)
 gather_sorted_kernel(const u64* __restrict__ keys, const float4* __restrict__ rowbox, const int* __restrict__ count,
-                     int rows, int n_pad, float4* __restrict__ sbox, int* __restrict__ srow) {
+                     int rows, int n_pad, bool complemented, float4* __restrict__ sbox, int* __restrict__ srow) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad || i >= count[b]) return;
-    const int row = (int)(uint32_t)keys[(size_t)b * n_pad + i];
+    int row = (int)(uint32_t)keys[(size_t)b * n_pad + i];
+    if (complemented) row = ~row;
     srow[(size_t)b * n_pad + i] = row;
     sbox[(size_t)b * n_pad + i] = rowbox[(size_t)b * rows + row];
 }
@@ -412,6 +422,16 @@ __device__ __forceinline__ bool suppresses(const float4 a, const float4 c, float
     const float uni = a.z * a.w + c.z * c.w - inter;
     const float iou = inter / uni;
     return !(iou < thr);
+}
+
+// The validation metric's rule (train_class.py:79-80: corner boxes with x_max = x_min + w go to
+// torchvision.ops.nms with threshold 1 - iou_threshold): areas from the corner differences, a
+// candidate is suppressed iff IoU > threshold, so a NaN IoU survives.
+__device__ __forceinline__ bool suppresses_corner(const float4 a, const float4 c, float thr) {
+    const float ax2 = a.x + a.z, ay2 = a.y + a.w, cx2 = c.x + c.z, cy2 = c.y + c.w;
+    const float inter = fmaxf(fminf(ax2, cx2) - fmaxf(a.x, c.x), 0.0f) * fmaxf(fminf(ay2, cy2) - fmaxf(a.y, c.y), 0.0f);
+    const float iou = inter / ((ax2 - a.x) * (ay2 - a.y) + (cx2 - c.x) * (cy2 - c.y) - inter);
+    return iou > thr;
 }
 
 constexpr int MASK_WAVES = 4;
@@ -463,7 +483,8 @@ __global__ void __launch_bounds__(256) iou_pairs_kernel(const float4* __restrict
 // Rows already suppressed by earlier chunks (bit set in `removed`) are skipped.
 __global__ void __launch_bounds__(64 * MASK_WAVES)
 iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, const u64* __restrict__ removed,
-                int n_pad, int row_begin, int row_end, float thr, u64* __restrict__ mask, size_t mask_stride_img) {
+                int n_pad, int row_begin, int row_end, float thr, int corner_rule, u64* __restrict__ mask,
+                size_t mask_stride_img) {
     __shared__ float4 cols[MASK_WAVES][64];
     __shared__ float4 colx[MASK_WAVES][64];
     __shared__ u64 col_special[MASK_WAVES];
@@ -534,7 +555,7 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
                 u64 amb = (~(keep_sure | sup) | row_special | (((cspec >> j) & 1ull) ? ~0ull : 0ull)) & live_mask;
                 if (amb) {
                     const bool mine = (amb >> lane) & 1ull;
-                    const u64 exact = __ballot(mine && suppresses(a, c, thr));
+                    const u64 exact = __ballot(mine && (corner_rule ? suppresses_corner(a, c, thr) : suppresses(a, c, thr)));
                     sup = (sup & ~amb) | exact;
                 }
                 w32 = shift_in(w32, sup);
@@ -694,7 +715,12 @@ emit_rows_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdi
         for (int k = lane; k < kdim; k += 64) {
             float v = src[k];
             if (SRC == 1) v = decode_value(g, s, k, a, y, x, v);
-            if (SRC != 2 && k < 4) {
+            if (SRC >= 3 && k < 4) {
+                // train_class.py:340,79,82: x_min = cx - w/2 ; w' = (x_min + w) - x_min
+                const float wh = src[k < 2 ? k + 2 : k];
+                const float lo = SRC == 3 ? src[k < 2 ? k : k - 2] - wh / 2.0f : src[k < 2 ? k : k - 2];
+                v = k < 2 ? lo : (lo + wh) - lo;
+            } else if (SRC != 2 && k < 4) {
                 // x_min = cx - w/2 ; cx' = x_min + w/2 ; scaled.  Same roundings as the reference.
                 if (k < 2) {
                     float wh = src[k + 2];
@@ -707,6 +733,63 @@ emit_rows_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdi
             }
             dst[k] = v;
         }
+    }
+}
+
+// Index of the first maximum of v[0..n) (torch.argmax on a row without NaN).
+__device__ __forceinline__ int first_argmax(const float* v, int n) {
+    int best = 0;
+    float m = v[0];
+    for (int k = 1; k < n; ++k)
+        if (v[k] > m) { m = v[k]; best = k; }
+    return best;
+}
+
+constexpr int MATCH_MAX_PRED = 1024;
+
+// True/false positive counting of the validation metric (train_class.py:347-360), one workgroup
+// per image.  kept: (B, max_keep, K) rows (x_min,y_min,w,h,conf,cls..) after NMS; labels:
+// (B, lmax, K) rows (cx,cy,w,h,conf,cls..).  A label is found when any kept row of its class
+// overlaps it with IoU > thr (train_class.py:67-74 arithmetic); one found label = one true positive.
+// out: (B, 3) int32 = (tp, fn, fp) with fn = labels - tp and fp = kept - tp.
+__global__ void __launch_bounds__(256)
+metric_match_kernel(const float* __restrict__ kept, const int* __restrict__ keep_count, int max_keep,
+                    const float* __restrict__ labels, const int* __restrict__ n_label, int lmax, int kdim, float thr,
+                    int* __restrict__ out) {
+    __shared__ float4 pbox[MATCH_MAX_PRED];
+    __shared__ int pcls[MATCH_MAX_PRED];
+    __shared__ int tp;
+    const int b = blockIdx.x;
+    const int nk = min(keep_count[b], max_keep);
+    const int nl = min(n_label[b], lmax);
+    if (threadIdx.x == 0) tp = 0;
+    for (int j = threadIdx.x; j < nk; j += 256) {
+        const float* r = kept + ((size_t)b * max_keep + j) * kdim;
+        pbox[j] = make_float4(r[0], r[1], r[2], r[3]);
+        pcls[j] = first_argmax(r + 5, kdim - 5);
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < nl; l += 256) {
+        const float* r = labels + ((size_t)b * lmax + l) * kdim;
+        const float lw = r[2], lh = r[3];
+        const float lx = r[0] - lw / 2.0f, ly = r[1] - lh / 2.0f;       // train_class.py:341
+        const int cls = first_argmax(r + 5, kdim - 5);
+        bool found = false;
+        for (int j = 0; j < nk; ++j) {
+            const float4 p = pbox[j];
+            const float x1 = fmaxf(p.x, lx), y1 = fmaxf(p.y, ly);
+            const float x2 = fminf(p.x + p.z, lx + lw), y2 = fminf(p.y + p.w, ly + lh);
+            const float inter = fmaxf(x2 - x1, 0.0f) * fmaxf(y2 - y1, 0.0f);
+            const float iou = inter / (p.z * p.w + lw * lh - inter);
+            found = found || (iou > thr && pcls[j] == cls);
+        }
+        if (found) atomicAdd(&tp, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[3 * b] = tp;
+        out[3 * b + 1] = nl - tp;
+        out[3 * b + 2] = nk - tp;
     }
 }
 
@@ -789,15 +872,15 @@ int sort_keys(u64* keys, int batch, int n_pad, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-int run_nms(const Workspace& w, const int* count, int batch, int n_pad, float iou_thr, int* out_idx, int* out_count,
-            int max_keep, hipStream_t st) {
+int run_nms(const Workspace& w, const int* count, int batch, int n_pad, float iou_thr, int corner_rule, int* out_idx,
+            int* out_count, int max_keep, hipStream_t st) {
     const int words = n_pad / 64;
     for (int r0 = 0; r0 < n_pad; r0 += w.chunk_rows) {
         const int r1 = r0 + w.chunk_rows < n_pad ? r0 + w.chunk_rows : n_pad;
         const int gx = (words + MASK_WAVES - 1) / MASK_WAVES, gy = (r1 - r0) / 64;
         dim3 grid(gx < 8 ? gx : 8, gy < 32 ? gy : 32, batch);
-        iou_mask_kernel<<<grid, 64 * MASK_WAVES, 0, st>>>(w.sbox, count, w.removed, n_pad, r0, r1, iou_thr, w.mask,
-                                                           w.mask_stride_img);
+        iou_mask_kernel<<<grid, 64 * MASK_WAVES, 0, st>>>(w.sbox, count, w.removed, n_pad, r0, r1, iou_thr, corner_rule,
+                                                           w.mask, w.mask_stride_img);
         nms_scan_kernel<<<batch, SCAN_THREADS, (size_t)words * 8, st>>>(w.mask, w.mask_stride_img, count, w.srow,
                                                                         w.removed, n_pad, r0, r1, out_idx, out_count,
                                                                         max_keep);
@@ -847,8 +930,8 @@ int postprocess_impl(const float* pred, const DecodeGeom& g, int batch, int rows
         fs, g, rows, kdim, rows_stage, conf_thr, w.rowbox, w.keys, n_pad, w.count);
     if ((rc = sort_keys(w.keys, batch, n_pad, st))) return rc;
     gather_sorted_kernel<<<dim3((n_pad + 255) / 256, batch), 256, 0, st>>>(w.keys, w.rowbox, w.count, rows, n_pad,
-                                                                           w.sbox, w.srow);
-    if ((rc = run_nms(w, w.count, batch, n_pad, iou_thr, out_idx, out_count, max_keep, st))) return rc;
+                                                                           SRC >= 3, w.sbox, w.srow);
+    if ((rc = run_nms(w, w.count, batch, n_pad, iou_thr, SRC >= 3, out_idx, out_count, max_keep, st))) return rc;
     if (cand_count)
         if ((rc = (int)hipMemcpyAsync(cand_count, w.count, (size_t)batch * 4, hipMemcpyDeviceToDevice, st))) return rc;
     if (out_rows) {
@@ -958,6 +1041,35 @@ int odamd_nms_rows(const float* rows_xywh, int batch, int rows, int kdim, float 
                                out_count, nullptr, max_keep, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int odamd_metric_nms(const float* pred, int batch, int rows, int kdim, float conf_thr, float nms_thr, int n_pad,
+                     float* out_rows, int* out_idx, int* out_count, int* cand_count, int max_keep, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (!pred) return ODAMD_E_ARG;
+    DecodeGeom g = {};
+    return postprocess_impl<3>(pred, g, batch, rows, kdim, conf_thr, nms_thr, nullptr, n_pad, out_rows, out_idx,
+                               out_count, cand_count, max_keep, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int odamd_metric_nms_rows(const float* rows_xywh, int batch, int rows, int kdim, float nms_thr, int n_pad,
+                          float* out_rows, int* out_idx, int* out_count, int max_keep, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    if (!rows_xywh) return ODAMD_E_ARG;
+    DecodeGeom g = {};
+    return postprocess_impl<4>(rows_xywh, g, batch, rows, kdim, 0.0f, nms_thr, nullptr, n_pad, out_rows, out_idx,
+                               out_count, nullptr, max_keep, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int odamd_metric_match(const float* kept_rows, const int* keep_count, int max_keep, const float* labels,
+                       const int* n_label, int lmax, int batch, int kdim, float iou_thr, int* counts, void* stream) {
+    if (!kept_rows || !keep_count || !labels || !n_label || !counts || batch < 1 || kdim < 6 || lmax < 1 ||
+        max_keep < 1)
+        return ODAMD_E_ARG;
+    if (max_keep > MATCH_MAX_PRED) return ODAMD_E_SHAPE;
+    metric_match_kernel<<<batch, 256, 0, (hipStream_t)stream>>>(kept_rows, keep_count, max_keep, labels, n_label, lmax,
+                                                               kdim, iou_thr, counts);
+    return (int)hipGetLastError();
+}
+
 int odamd_iou_pairs(const float* a_xywh, int na, const float* b_xywh, int nb, float* out, int n, void* stream) {
     if (!a_xywh || !b_xywh || !out || n < 1 || na < 1 || nb < 1) return ODAMD_E_ARG;
     if ((na != 1 && na < n) || (nb != 1 && nb < n)) return ODAMD_E_SHAPE;
@@ -974,7 +1086,7 @@ int odamd_iou_mask(const float* boxes_xywh, int n, float iou_thr, uint64_t* mask
     const int gx = (words + MASK_WAVES - 1) / MASK_WAVES;
     dim3 grid(gx < 8 ? gx : 8, words < 64 ? words : 64, 1);
     iou_mask_kernel<<<grid, 64 * MASK_WAVES, 0, (hipStream_t)stream>>>((const float4*)boxes_xywh, nullptr, nullptr, n, 0,
-                                                                       n, iou_thr, (u64*)mask, 0);
+                                                                       n, iou_thr, 0, (u64*)mask, 0);
     return (int)hipGetLastError();
 }
 

@@ -146,3 +146,44 @@ def nms_rows(rows, iou_threshold, max_keep=None, n_pad=0):
     check(lib.odamd_nms_rows(_ptr(rows), b, n, k, float(iou_threshold), n_pad, _ptr(out), _ptr(idx), _ptr(cnt),
                              max_keep, _ptr(ws), ws.numel(), _stream()), 'nms_rows')
     return PostResult(out, idx, cnt, cnt)
+
+
+def metric_nms(pred, confidence_threshold, iou_threshold, max_keep=100, n_pad=0):
+    """Candidate selection and NMS of the validation metric (train_class.py:340-346, :76-83) on the
+    NON-deployed (B,R,K) float32 CUDA prediction (not modified).  `iou_threshold` is the metric's
+    argument; the suppression threshold handed to the NMS is 1 - iou_threshold as in the reference."""
+    if pred.dtype != torch.float32 or not pred.is_cuda or pred.dim() != 3:
+        raise ValueError('pred must be a (B,R,K) float32 CUDA tensor')
+    pred = pred.contiguous()
+    b, r, k = pred.shape
+    ws = _workspace(lib.odamd_postprocess_workspace_bytes(b, r, k, n_pad), pred.device)
+    rows, idx, cnt, cand = _outputs(b, k, max_keep, pred.device)
+    check(lib.odamd_metric_nms(_ptr(pred), b, r, k, float(confidence_threshold), float(1 - iou_threshold), n_pad,
+                               _ptr(rows), _ptr(idx), _ptr(cnt), _ptr(cand), max_keep, _ptr(ws), ws.numel(), _stream()),
+          'metric_nms')
+    return PostResult(rows, idx, cnt, cand)
+
+
+def metric_nms_rows(rows, iou_threshold, max_keep=None, n_pad=0):
+    """Stand-alone train_class.nms (train_class.py:77-83) on (B,N,K) or (N,K) float32 CUDA rows
+    (x_min,y_min,w,h,conf,cls..); suppression threshold 1 - iou_threshold as in the reference."""
+    if rows.dim() == 2:
+        rows = rows.unsqueeze(0)
+    rows = rows.contiguous()
+    b, n, k = rows.shape
+    max_keep = max_keep or n
+    ws = _workspace(lib.odamd_postprocess_workspace_bytes(b, n, k, n_pad), rows.device)
+    out, idx, cnt, _ = _outputs(b, k, max_keep, rows.device)
+    check(lib.odamd_metric_nms_rows(_ptr(rows), b, n, k, float(1 - iou_threshold), n_pad, _ptr(out), _ptr(idx), _ptr(cnt),
+                                    max_keep, _ptr(ws), ws.numel(), _stream()), 'metric_nms_rows')
+    return PostResult(out, idx, cnt, cnt)
+
+
+def metric_match(result, labels, n_label, iou_threshold):
+    """(tp, fn, fp) per image, (B,3) int32 on the device (train_class.py:347-365).  `result`: PostResult of
+    metric_nms; labels: (B,lmax,K) float32 CUDA rows (cx,cy,w,h,conf,cls..); n_label: (B,) int32."""
+    b, max_keep, k = result.rows.shape
+    out = torch.empty((b, 3), dtype=torch.int32, device=result.rows.device)
+    check(lib.odamd_metric_match(_ptr(result.rows), _ptr(result.count), max_keep, _ptr(labels), _ptr(n_label),
+                                 labels.shape[1], b, k, float(iou_threshold), _ptr(out), _stream()), 'metric_match')
+    return out

@@ -2,22 +2,26 @@
 path: train_class (model / optimizer / loss / EMA / data-parallel wiring and the step loop),
 loss_class, focal_loss (folded into loss_class), model_ema, lr_adjust, plus a synthetic dataset.
 
-Reference: train_class.py:15-51 (wiring), :158-171 (optimizer), :177-294 (loop), :397-474 (loss),
-:477-499 (EMA), :502-521 (LR).  Image decoding / augmentation (`torch_dataset.__getitem__`),
-validation metric, wandb and pruning surgery are outside this build; the label -> grid assignment
-rule (train_class.py:578-607) is restated in `assign_labels` for synthetic labels.
+Reference: train_class.py:15-51 (wiring), :66-83 (iou / nms), :158-171 (optimizer), :177-294 (loop),
+:296-365 (validation / metric), :397-474 (loss), :477-499 (EMA), :502-521 (LR).  Image decoding /
+augmentation (`torch_dataset.__getitem__`), wandb and pruning surgery are outside this build; the
+label -> grid assignment rule (train_class.py:578-607) is restated in `assign_labels` for synthetic
+labels.
 
 One training step = forward (train-mode BN) -> loss (+ gradient) -> backward -> bucketed gradient
 all-reduce (RCCL, overlapped with backward) -> fused Adam + EMA; every arithmetic step is a HIP
 kernel of libodamd.so.
 """
+import ctypes as C
 import math
 import os
 
 import numpy as np
 import torch
 
+from . import postprocess as _post
 from . import train_engine as te
+from ._lib import lib, check
 from .model.layer import decode
 
 
@@ -50,7 +54,12 @@ class loss_class:
         """`screen_list` may also be a DeviceAssignment (then `label_expend` is not used)."""
         plan = getattr(pred, '_odamd_plan', None)
         if plan is None:
-            raise RuntimeError('loss_class needs the prediction of a training-mode objectdetection_amd yolov7')
+            # an eval-mode prediction (validation, train_class.py:311): value only, no gradient
+            if pred.requires_grad:
+                raise RuntimeError('loss_class differentiates only the prediction of a training-mode '
+                                   'objectdetection_amd yolov7')
+            out = te.detection_loss(pred, screen_list, label_expend, self.label_smooth)
+            return out[0], out[1], out[2], out[3]
         out = _LossFn.apply(pred, plan, screen_list, label_expend, self.label_smooth)
         return out[0], out[1], out[2], out[3]
 
@@ -288,7 +297,7 @@ class synthetic_dataset(torch.utils.data.Dataset):
 class train_class:
     """Wiring and step loop of the reference's train_class (train_class.py:15-51, :177-294)."""
 
-    def __init__(self, args, dataloader=None):
+    def __init__(self, args, dataloader=None, val_dataloader=None):
         if not torch.cuda.is_available():
             raise RuntimeError('objectdetection_amd.train_class needs a GPU: there is no CPU fallback')
         self.args = args
@@ -298,6 +307,7 @@ class train_class:
         # --amp (train_class.py:29, fp16 autocast in the reference) selects the bf16 mixed-precision step
         self.model.train_dtype = 'bf16' if getattr(args, 'amp', False) else 'f32'
         self.train_dataloader = dataloader if dataloader is not None else self.dataloader_load()
+        self.val_dataloader = val_dataloader if val_dataloader is not None else self.dataloader_load(val=True)
         self.optimizer, self.optimizer_adjust = self.optimizer_load()
         self.loss = loss_class(args)
         self.ema = None
@@ -328,9 +338,34 @@ class train_class:
         return {'model': yolov7(args), 'epoch_finished': 0, 'optimizer_state_dict': None, 'ema_update': 0,
                 'standard': 0}
 
-    def dataloader_load(self):
+    # ---- train_class.py:66-83 ---------------------------------------------------------------------
+    @staticmethod
+    def iou(pred, label):
+        """IoU of (x_min,y_min,w,h) CUDA rows, `label` usually a single row (train_class.py:67-74)."""
+        a = pred[:, 0:4].float().contiguous()
+        b = label[:, 0:4].float().contiguous().to(a.device)
+        n = max(len(a), len(b))
+        out = torch.empty(n, dtype=torch.float32, device=a.device)
+        check(lib.odamd_iou_pairs(a.data_ptr(), len(a), b.data_ptr(), len(b), out.data_ptr(), n, te._stream()),
+              'iou_pairs')
+        return out
+
+    @staticmethod
+    def nms(pred, iou_threshold):
+        """(N,K) CUDA rows (x_min,y_min,w,h,conf,cls..) -> kept rows, best score first (train_class.py:77-83).
+        Unlike the reference, `pred` itself is left unchanged."""
+        if len(pred) == 0:
+            return pred
+        res = _post.metric_nms_rows(pred.float(), iou_threshold)
+        return res.rows[0, :int(res.count[0])]
+
+    def dataloader_load(self, val=False):
         args = self.args
         n = getattr(args, 'synthetic_images', args.batch * 8)
+        if val:
+            ds = synthetic_dataset(args, getattr(args, 'synthetic_val_images', args.batch * 2), seed=4242)
+            return torch.utils.data.DataLoader(ds, batch_size=args.batch, shuffle=False, drop_last=False,
+                                               collate_fn=ds.collate_fn, num_workers=getattr(args, 'num_worker', 0))
         ds = synthetic_dataset(args, n)
         sampler = torch.utils.data.distributed.DistributedSampler(ds) if args.distributed else None
         return torch.utils.data.DataLoader(ds, batch_size=args.batch, shuffle=sampler is None, drop_last=True,
@@ -364,6 +399,58 @@ class train_class:
         self.optimizer = self.optimizer_adjust(self.optimizer)
         return torch.stack(losses).detach()
 
+    # ---- train_class.py:296-365 -------------------------------------------------------------------
+    def metric(self, pred_batch, label_list, confidence_threshold, iou_threshold):
+        """(tp, fn, fp) of one batch.  pred_batch: (B,R,K) CUDA prediction of the eval-mode model
+        (cx,cy,w,h,raw conf,raw cls..; not modified, the reference shifts it in place); label_list:
+        one (L_b,K) tensor per image (cx,cy,w,h,conf,cls..).  Candidate selection, NMS, the top-100
+        cut and the matching all run on the device; three integers come back."""
+        return tuple(int(v) for v in self.metric_device(pred_batch, label_list, confidence_threshold,
+                                                         iou_threshold).sum(0).tolist())
+
+    def metric_device(self, pred_batch, label_list, confidence_threshold, iou_threshold):
+        """Same, left on the device: (B,3) int32 rows (tp, fn, fp) per image, no host synchronisation."""
+        dev = pred_batch.device
+        b, _, k = pred_batch.shape
+        lmax = max(1, max((len(l) for l in label_list), default=1))
+        packed = torch.zeros((b, lmax, k), dtype=torch.float32)
+        counts = torch.zeros(b, dtype=torch.int32)
+        for i, lab in enumerate(label_list):
+            packed[i, :len(lab)] = lab
+            counts[i] = len(lab)
+        packed, counts = packed.to(dev, non_blocking=True), counts.to(dev, non_blocking=True)
+        res = _post.metric_nms(pred_batch.float(), confidence_threshold, iou_threshold, max_keep=100)
+        return _post.metric_match(res, packed, counts, iou_threshold)
+
+    def validation(self):
+        """One pass over the validation loader with the EMA weights when enabled: mean loss, precision,
+        recall and the reference's 'm_ap' = precision * recall (train_class.py:296-333)."""
+        args = self.args
+        with torch.no_grad():
+            model = self.ema.ema_model.eval() if self.ema else self.model.eval()
+            model._plans = {}       # inference plans hold folded copies of the weights: rebuild from the current ones
+            loss_sum = torch.zeros((), device=args.device)
+            counts = torch.zeros(3, dtype=torch.int64, device=args.device)
+            steps = 0
+            for image_batch, screen_list, label_expend, label_list in self.val_dataloader:
+                image_batch = image_batch.to(args.device, non_blocking=True)
+                pred_batch = model(image_batch)
+                loss_sum += self.loss(pred_batch, screen_list, label_expend)[0]
+                counts += self.metric_device(pred_batch, label_list, args.confidence_threshold,
+                                             args.iou_threshold).sum(0)
+                steps += 1
+            val_loss = float(loss_sum) / max(steps, 1)                       # the pass's only host reads
+            tp, fn, fp = counts.tolist()
+            precision = tp / (tp + fp + 1e-6)
+            recall = tp / (tp + fn + 1e-6)
+            m_ap = precision * recall
+            if getattr(args, 'print_info', True):
+                print(f'| val | val_loss:{val_loss:.4f} | threshold:{args.confidence_threshold:.2f}+'
+                      f'{args.iou_threshold:.2f} | val_precision:{precision:.4f} | val_recall:{recall:.4f} |'
+                      f' val_m_ap:{m_ap:.4f} |')
+        self.model.train()
+        return val_loss, precision, recall, m_ap
+
     def train(self):
         args = self.args
         history = []
@@ -383,15 +470,25 @@ class train_class:
                       f' confidence_loss:{means[2]:.4f} | class_loss:{means[3]:.4f} |'
                       f' lr:{self.optimizer.param_groups[0]["lr"]:.6f} |')
             if args.local_rank == 0:
+                validate = len(self.val_dataloader) > 0 and hasattr(args, 'confidence_threshold')
+                if validate:                                   # one rank validates (train_class.py:258)
+                    val_loss, precision, recall, m_ap = self.validation()
+                    self.model_dict.update(val_loss=val_loss, val_precision=precision, val_recall=recall, val_m_ap=m_ap)
                 self.model_dict['epoch_finished'] = epoch
                 self.model_dict['train_loss'] = means[0]
                 self.model_dict['ema_update'] = self.ema.update_total if self.ema else self.model_dict['ema_update']
-                save = getattr(args, 'save_path', None)
-                if save and (epoch % getattr(args, 'save_epoch', 5) == 0 or epoch == args.epoch):
+                save, best = getattr(args, 'save_path', None), getattr(args, 'save_best', None)
+                is_best = validate and m_ap >= self.model_dict['standard'] and m_ap >= 0.25   # train_class.py:274
+                if is_best:
+                    self.model_dict['standard'] = m_ap
+                if (save and (epoch % getattr(args, 'save_epoch', 5) == 0 or epoch == args.epoch)) or (best and is_best):
                     out = dict(self.model_dict)
                     out['model'] = self.ema.ema_model if self.ema else self.model
                     out['optimizer_state_dict'] = self.optimizer.state_dict()
-                    torch.save(out, save)
+                    if save and (epoch % getattr(args, 'save_epoch', 5) == 0 or epoch == args.epoch):
+                        torch.save(out, save)
+                    if best and is_best:
+                        torch.save(out, best)
             if args.distributed:
                 torch.distributed.barrier()
         return history

@@ -138,6 +138,47 @@ class GradReducer:
         return 1.0 / self.world
 
 
+def _pack_positives(screen_list, label_expend, dev):
+    """Host lists of the reference's collate format -> device arrays (row, image, label row) per positive."""
+    idx, img = [], []
+    for b, s in enumerate(screen_list):
+        if len(s):
+            idx.append(s.to(torch.int32))
+            img.append(torch.full((len(s),), b, dtype=torch.int32))
+    n_pos = sum(len(i) for i in idx)
+    if not n_pos:
+        return 0, None, None, None, None
+    screen = torch.cat(idx).to(dev)
+    simg = torch.cat(img).to(dev)
+    label = label_expend.to(dev, torch.float32).contiguous()
+    return n_pos, screen.data_ptr(), simg.data_ptr(), label.data_ptr(), (screen, simg, label)
+
+
+def detection_loss(pred, screen_list, label_expend, label_smooth):
+    """loss_class.__call__ (train_class.py:397-474) on any (B,R,K) float32 CUDA prediction, value only
+    (the validation loss, train_class.py:311).  Returns a (4,) device tensor."""
+    if pred.dtype != torch.float32 or not pred.is_cuda or pred.dim() != 3:
+        raise ValueError('pred must be a (B,R,K) float32 CUDA tensor')
+    pred = pred.contiguous()
+    dev = pred.device
+    b, r, k = pred.shape
+    scratch = torch.empty_like(pred)            # the kernels flag positives in the gradient buffer
+    out = torch.empty(4, dtype=torch.float32, device=dev)
+    ws = torch.empty(int(lib.odamd_loss_workspace_bytes()), dtype=torch.uint8, device=dev)
+    if hasattr(screen_list, 'n_pos'):
+        a = screen_list
+        check(lib.odamd_detection_loss_dev(pred.data_ptr(), scratch.data_ptr(), a.screen.data_ptr(),
+                                           a.screen_img.data_ptr(), a.label.data_ptr(), b, r, k, a.n_pos.data_ptr(),
+                                           a.capacity, float(label_smooth), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           _stream()), 'detection_loss_dev')
+        return out
+    n_pos, sp, ip, lp, keep = _pack_positives(screen_list, label_expend, dev)
+    check(lib.odamd_detection_loss(pred.data_ptr(), scratch.data_ptr(), sp, ip, lp, b, r, k, n_pos, float(label_smooth),
+                                   out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), 'detection_loss')
+    out._keep = keep
+    return out
+
+
 class TrainPlan:
     """Forward (train mode) + backward launch lists for one (batch, size, dtype)."""
 
@@ -461,20 +502,7 @@ class TrainPlan:
                                                self.loss_ws.data_ptr(), self.loss_ws.numel(), _stream()),
                   'detection_loss_dev')
             return self.loss_out
-        idx, img = [], []
-        for b, s in enumerate(screen_list):
-            if len(s):
-                idx.append(s.to(torch.int32))
-                img.append(torch.full((len(s),), b, dtype=torch.int32))
-        n_pos = sum(len(i) for i in idx)
-        if n_pos:
-            screen = torch.cat(idx).to(dev)
-            simg = torch.cat(img).to(dev)
-            label = label_expend.to(dev, torch.float32).contiguous()
-            sp, ip, lp = screen.data_ptr(), simg.data_ptr(), label.data_ptr()
-            self._keep_loss = (screen, simg, label)
-        else:
-            sp = ip = lp = None
+        n_pos, sp, ip, lp, self._keep_loss = _pack_positives(screen_list, label_expend, dev)
         b, r, k = self.pred.shape
         check(lib.odamd_detection_loss(self.pred.data_ptr(), self.dpred.data_ptr(), sp, ip, lp, b, r, k, n_pos,
                                        float(label_smooth), self.loss_out.data_ptr(), self.loss_ws.data_ptr(),
