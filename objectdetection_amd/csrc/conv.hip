@@ -188,7 +188,7 @@ __host__ __device__ constexpr int max_in_pix(int ks, int st, int pg) {
 // before the loop.  POOL (2x2 max pool on load) stages synchronously instead.
 // Epilogue: each wave transposes its 32-pixel x (32*CGW)-channel results through a private LDS
 // slice so that global stores are 16 bytes per lane and whole 64..256-byte runs per pixel.
-template <int DT, int KS, int ST, int CG, int PG, int WP, int WC, int CKB, bool POOL>
+template <int DT, int KS, int ST, int CG, int PG, int WP, int WC, int CKB, bool POOL, bool UPSKIP = false>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
     constexpr int ES = Elem<DT>::SIZE;
     constexpr int TAPS = KS * KS;
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
     for (int i = 0; i < PGW; ++i) {
         const int q = (wp * PGW + i) * 32 + r;
         int ty = q / p.TW, tx = q - ty * p.TW;
-        if (KS == 3 && ST == 1 && p.upskip) {
+        if (UPSKIP) {
             // zero-upsampled input: group g holds pixels of one (row parity, column parity) class
             // g & 3, so that whole MFMA groups can skip the taps that land on inserted zeros
             const int g = wp * PGW + i, hw = p.TW >> 1;
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
                 for (int i = 0; i < PGW; ++i) bb[i] = *(const u32x4*)(lds_in + b_off[i] + tap_off + s * 32);
 #pragma unroll
                 for (int i = 0; i < PGW; ++i) {
-                    if (KS == 3 && ST == 1 && p.upskip) {
+                    if (UPSKIP) {
                         // tap (ky, kx) meets data only where (row + ky) and (column + kx) are odd
                         const int g = wp * PGW + i;
                         if (!((((g >> 1) + tap / KS) & 1) && ((g + tap % KS) & 1))) continue;
@@ -888,6 +888,12 @@ int launch_conv(ConvP p, hipStream_t st) {
     size_t lds = (((size_t)t.ih * t.iw * PS + 255) & ~(size_t)255) + w_bytes;
     const size_t epi = (size_t)4 * 32 * ((CG / WC) * 32 * 4 + 16);    // the waves' f32 transpose slices
     if (lds < epi) lds = epi;
+    if constexpr (KS == 3 && ST == 1 && PG % 4 == 0 && !POOL) {
+        if (p.upskip) {
+            conv_igemm_kernel<DT, KS, ST, CG, PG, WP, WC, CKB, POOL, true><<<p.nblocks, 256, lds, st>>>(p);
+            return (int)hipGetLastError();
+        }
+    }
     conv_igemm_kernel<DT, KS, ST, CG, PG, WP, WC, CKB, POOL><<<p.nblocks, 256, lds, st>>>(p);
     return (int)hipGetLastError();
 }
@@ -950,7 +956,13 @@ int dispatch_conv(const ConvP& p, int ks, int stride, hipStream_t st) {
         if (cin_bytes % 64 == 0) return dispatch_cg<DT, 1, 1, 64, false>(p, st);
         return dispatch_cg<DT, 1, 1, 32, false>(p, st);
     }
-    if (ks == 3 && stride == 1) return dispatch_cg<DT, 3, 1, 32, false>(p, st);
+    if (ks == 3 && stride == 1) {
+        if (DT == ODAMD_DTYPE_BF16 && cin_bytes % 64 == 0 && p.Cout <= 64 && !p.upz) {
+            if (p.Cout <= 32) return launch_conv<DT, 3, 1, 1, 8, 4, 1, 64, false>(p, st);
+            return launch_conv<DT, 3, 1, 2, 8, 4, 1, 64, false>(p, st);
+        }
+        return dispatch_cg<DT, 3, 1, 32, false>(p, st);
+    }
     if (ks == 3 && stride == 2) return dispatch_cg<DT, 3, 2, 32, false>(p, st);
     return ODAMD_E_ARG;
 }
