@@ -24,4 +24,11 @@ __device__ __forceinline__ uint32_t f32x2_to_bf16x2(float a, float b) {
 }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
+// 1 / (1 + exp(-z)) from the hardware exp2 and reciprocal (about 1 ulp each, two quarter-rate
+// instructions and two full-rate ones); for kernels whose results are rounded to bf16.  The library
+// forms (__expf, __frcp_rn, operator/) expand to range fix-ups and a full IEEE division sequence.
+__device__ __forceinline__ float sigmoid_fast(float z) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
+}
+
 #endif

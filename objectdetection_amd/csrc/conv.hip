@@ -65,7 +65,7 @@ __device__ __forceinline__ uint4 vmax16(const uint4& p, const uint4& q, int dt) 
 template <int DT>
 __device__ __forceinline__ float silu(float v) {
     if constexpr (DT == ODAMD_DTYPE_F32) return v / (1.0f + expf(-v));
-    else return v * __frcp_rn(1.0f + __expf(-v));
+    else return v * sigmoid_fast(v);
 }
 
 // NHWC epilogue shared by the convolution kernels.  `acc[i][j]`: the wave's results for pixel

@@ -25,7 +25,7 @@ __device__ __forceinline__ float silu_grad(float z) {
 // bf16 kernels round their results to 8 mantissa bits: hardware exp / reciprocal are plenty
 template <int DT> __device__ __forceinline__ float sigmoid_t(float z) {
     if constexpr (DT == ODAMD_DTYPE_F32) return 1.0f / (1.0f + expf(-z));
-    else return __frcp_rn(1.0f + __expf(-z));
+    else return sigmoid_fast(z);
 }
 template <int DT> __device__ __forceinline__ float silu_t(float z) {
     if constexpr (DT == ODAMD_DTYPE_F32) return silu_f(z);
