@@ -537,6 +537,48 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
         const u64 cspec = ((u64)__builtin_amdgcn_readfirstlane((uint32_t)(cs_ >> 32)) << 32) |
                           __builtin_amdgcn_readfirstlane((uint32_t)cs_);
         uint32_t half[2] = {0u, 0u};
+        if ((__ballot(live && ae.special != 0.0f) | cspec) == 0ull && thr_ok) {
+            // Common case, every box of the tile regular.  Pairs that suppress are rare (a few in 10^5), so
+            // a column only tests "surely below the threshold" for all rows at once; the wave leaves
+            // this path for a column only when some row fails that test.
+            const float a_keep = live ? a_lo : __builtin_inff();   // idle lanes never ask for the second look
+            // Eight columns at a time without a branch between them (eight independent dependency
+            // chains keep the vector pipe busy); one test decides whether any of them needs the second look.
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                uint32_t w32 = 0;
+#pragma unroll 1
+                for (int j0 = 0; j0 < 32; j0 += 8) {
+                    u64 need[8];
+                    float inter[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = hh * 32 + j0 + u;
+                        const float4 c = cols[wave][j];
+                        const float4 e = colx[wave][j];
+                        const float x1 = vmax(a.x, c.x), y1 = vmax(a.y, c.y);
+                        const float x2 = vmin(ae.x2, e.x), y2 = vmin(ae.y2, e.y);
+                        inter[u] = vmax(x2 - x1, 0.0f) * vmax(y2 - y1, 0.0f);
+                        need[u] = __ballot(!(inter[u] < a_keep + e.z));
+                    }
+                    if ((need[0] | need[1] | need[2] | need[3] | need[4] | need[5] | need[6] | need[7]) == 0ull) continue;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (need[u] == 0ull) continue;
+                        const int j = hh * 32 + j0 + u;
+                        const float4 c = cols[wave][j];
+                        u64 sup = __ballot(inter[u] > a_hi + colx[wave][j].w) & need[u];
+                        const u64 amb = need[u] & ~sup;                 // inside the guard band: exact arithmetic
+                        if (amb) {
+                            const bool mine = (amb >> lane) & 1ull;
+                            sup |= __ballot(mine && (corner_rule ? suppresses_corner(a, c, thr) : suppresses(a, c, thr)));
+                        }
+                        w32 |= (uint32_t)((sup >> lane) & 1ull) << (j0 + u);
+                    }
+                }
+                half[hh] = w32;
+            }
+        } else {
 #pragma unroll
         for (int hh = 1; hh >= 0; --hh) {
             uint32_t w32 = 0;
@@ -561,6 +603,7 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
                 w32 = shift_in(w32, sup);
             }
             half[hh] = w32;
+        }
         }
         word = ((u64)half[1] << 32) | half[0];
         const int ncol = n - ct * 64;                                     // valid columns of this tile
