@@ -649,26 +649,33 @@ conv_first_kernel(const float* __restrict__ img, const float* __restrict__ w, co
 #pragma unroll
             for (int e = 0; e < 8; ++e) wb[e] = (short)f32_to_bf16(wa[e]);
         }
-        for (int g = wave; g < TH * (TW / 16); g += 4) {
-            const int ty = g / (TW / 16), tx = (g % (TW / 16)) * 16 + j;
-            const float* pp = patch + ty * PW + tx;
+        // wave w owns the 16-pixel column strip w of every tile row (TW / 16 == 4 waves): the lane's
+        // gather addresses are fixed and the row advances by an immediate offset in the unrolled loop
+        static_assert(TW / 16 == 4, "one strip per wave");
+        const int tx = wave * 16 + j;
+        const float* src[NK];
+#pragma unroll
+        for (int e = 0; e < NK; ++e) src[e] = patch + tx + off[e];
+#pragma unroll 2
+        for (int ty = 0; ty < TH; ++ty) {
             f32x4_t d = {0.f, 0.f, 0.f, 0.f};
             if constexpr (DT == ODAMD_DTYPE_F32) {
 #pragma unroll
-                for (int e = 0; e < NK; ++e) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[e], pp[off[e]], d, 0, 0, 0);
+                for (int e = 0; e < NK; ++e) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[e], src[e][ty * PW], d, 0, 0, 0);
             } else {
                 bf16x8_t xb;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) xb[e] = (short)f32_to_bf16(pp[off[e]]);
+                for (int e = 0; e < 8; ++e) xb[e] = (short)f32_to_bf16(src[e][ty * PW]);
                 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb, d, 0, 0, 0);
             }
             const int oy = oy0 + ty, ox = ox0 + tx;
             if (oy >= H || ox >= W) continue;
             float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float a = scale ? d[e] * sc[e] + sh[e] : d[e];
-                o[e] = act ? silu<DT>(a) : a;
+            for (int e = 0; e < 4; ++e) o[e] = scale ? d[e] * sc[e] + sh[e] : d[e];
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = silu<DT>(o[e]);
             }
             char* dst = y + ((((size_t)b * H + oy) * W + ox) * y_ld + cg + 4 * kg) * ES;
             if (cg + 4 * kg + 4 <= Cout) {
@@ -676,8 +683,8 @@ conv_first_kernel(const float* __restrict__ img, const float* __restrict__ w, co
                     *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
                 } else {
                     uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                    pk.x = f32x2_to_bf16x2(o[0], o[1]);
+                    pk.y = f32x2_to_bf16x2(o[2], o[3]);
                     *(uint2*)dst = pk;
                 }
             } else {
