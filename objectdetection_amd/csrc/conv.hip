@@ -115,9 +115,10 @@ __device__ __forceinline__ void nhwc_epilogue(const f32x16_t (&acc)[PGW][CGW], c
                 v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
             }
 #pragma unroll
-            for (int e = 0; e < CPL; ++e) {
-                const float t = v[e] * scl[e] + shf[e];
-                v[e] = act ? silu<DT>(t) : t;
+            for (int e = 0; e < CPL; ++e) v[e] = v[e] * scl[e] + shf[e];
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) v[e] = silu<DT>(v[e]);
             }
             if (op >= 0 && c_lane < Cout) {
                 char* dst = y + ((ybase + op) * y_ld + c_lane) * ES;
@@ -134,10 +135,10 @@ __device__ __forceinline__ void nhwc_epilogue(const f32x16_t (&acc)[PGW][CGW], c
                 if constexpr (DT == ODAMD_DTYPE_F32) {
                     pk = u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
                 } else {
-                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    pk.z = (uint32_t)f32_to_bf16(v[4 % CPL]) | ((uint32_t)f32_to_bf16(v[5 % CPL]) << 16);
-                    pk.w = (uint32_t)f32_to_bf16(v[6 % CPL]) | ((uint32_t)f32_to_bf16(v[7 % CPL]) << 16);
+                    pk.x = f32x2_to_bf16x2(v[0], v[1]);
+                    pk.y = f32x2_to_bf16x2(v[2], v[3]);
+                    pk.z = f32x2_to_bf16x2(v[4 % CPL], v[5 % CPL]);
+                    pk.w = f32x2_to_bf16x2(v[6 % CPL], v[7 % CPL]);
                 }
                 if (c_lane + CPL <= Cout) {
                     *(u32x4*)dst = pk;
@@ -663,10 +664,10 @@ conv_first_kernel(const float* __restrict__ img, const float* __restrict__ w, co
 #pragma unroll
                 for (int e = 0; e < NK; ++e) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[e], src[e][ty * PW], d, 0, 0, 0);
             } else {
-                bf16x8_t xb;
+                u32x4 xw;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) xb[e] = (short)f32_to_bf16(src[e][ty * PW]);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb, d, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) xw[e] = f32x2_to_bf16x2(src[2 * e][ty * PW], src[2 * e + 1][ty * PW]);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, __builtin_bit_cast(bf16x8_t, xw), d, 0, 0, 0);
             }
             const int oy = oy0 + ty, ox = ox0 + tx;
             if (oy >= H || ox >= W) continue;
