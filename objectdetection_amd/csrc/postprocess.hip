@@ -558,8 +558,12 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
                         const float4 e = colx[wave][j];
                         const float x1 = vmax(a.x, c.x), y1 = vmax(a.y, c.y);
                         const float x2 = vmin(ae.x2, e.x), y2 = vmin(ae.y2, e.y);
-                        inter[u] = vmax(x2 - x1, 0.0f) * vmax(y2 - y1, 0.0f);
-                        need[u] = __ballot(!(inter[u] < a_keep + e.z));
+                        // one clamp is enough for the keep test: with dx clamped, a negative dy makes the product
+                        // non-positive and the (positive) threshold decides "keep" as it must
+                        const float dy = y2 - y1;
+                        const float prod = vmax(x2 - x1, 0.0f) * dy;
+                        inter[u] = prod;
+                        need[u] = __ballot(!(prod < a_keep + e.z));
                     }
                     if ((need[0] | need[1] | need[2] | need[3] | need[4] | need[5] | need[6] | need[7]) == 0ull) continue;
 #pragma unroll
@@ -567,6 +571,7 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
                         if (need[u] == 0ull) continue;
                         const int j = hh * 32 + j0 + u;
                         const float4 c = cols[wave][j];
+                        // need => product >= threshold > 0 => dy > 0 (dx > 0): the product is the intersection
                         u64 sup = __ballot(inter[u] > a_hi + colx[wave][j].w) & need[u];
                         const u64 amb = need[u] & ~sup;                 // inside the guard band: exact arithmetic
                         if (amb) {
@@ -727,7 +732,11 @@ nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int*
 }
 
 // Kept rows -> output rows (predict.py:74-79).  SRC as in filter_kernel.  One wave per kept row:
-// the row's (scale, anchor, cell) is wave-uniform, lanes walk the K columns.
+// the row's (scale, anchor, cell) is wave-uniform, lanes walk the K columns.  A wave takes
+// EMIT_ROWS consecutive kept rows per trip and issues all their loads before the first use, so
+// that enough reads are in flight to cover the latency of HBM.
+constexpr int EMIT_ROWS = 4;
+
 template <int SRC>
 __global__ void __launch_bounds__(256)
 emit_rows_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdim, const int* __restrict__ keep_idx,
@@ -738,43 +747,62 @@ emit_rows_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdi
     const float xs = scale_xy ? scale_xy[2 * b] : 1.0f;
     const float ys = scale_xy ? scale_xy[2 * b + 1] : 1.0f;
     const int lane = threadIdx.x & 63;
-    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < nk; j += gridDim.x * 4) {
-        const int row = keep_idx[(size_t)b * max_keep + j];
-        const float* src;
-        int s = 0, a = 0, y = 0, x = 0;
-        if (SRC != 1) {
-            src = pred + ((size_t)b * rows + row) * kdim;
-        } else {
-            s = row >= g.rows_before[2] ? 2 : (row >= g.rows_before[1] ? 1 : 0);
-            const int lrow = row - g.rows_before[s];
-            const int hw = g.h[s] * g.w[s];
-            a = lrow / hw;
-            const int cell = lrow - a * hw;
-            y = cell / g.w[s];
-            x = cell - y * g.w[s];
-            src = g.head[s] + ((size_t)b * g.n_anchor * hw + lrow) * kdim;
-        }
-        float* dst = out + ((size_t)b * max_keep + j) * kdim;
-        for (int k = lane; k < kdim; k += 64) {
-            float v = src[k];
-            if (SRC == 1) v = decode_value(g, s, k, a, y, x, v);
-            if (SRC >= 3 && k < 4) {
-                // train_class.py:340,79,82: x_min = cx - w/2 ; w' = (x_min + w) - x_min
-                const float wh = src[k < 2 ? k + 2 : k];
-                const float lo = SRC == 3 ? src[k < 2 ? k : k - 2] - wh / 2.0f : src[k < 2 ? k : k - 2];
-                v = k < 2 ? lo : (lo + wh) - lo;
-            } else if (SRC != 2 && k < 4) {
-                // x_min = cx - w/2 ; cx' = x_min + w/2 ; scaled.  Same roundings as the reference.
-                if (k < 2) {
-                    float wh = src[k + 2];
-                    if (SRC == 1) wh = decode_value(g, s, k + 2, a, y, x, wh);
-                    const float half = wh / 2.0f;
-                    v = ((v - half) + half) * (k == 0 ? xs : ys);
-                } else {
-                    v = v * (k == 2 ? xs : ys);
-                }
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int j0 = wave * EMIT_ROWS; j0 < nk; j0 += gridDim.x * 4 * EMIT_ROWS) {
+        const float* src[EMIT_ROWS];
+        int s[EMIT_ROWS], a[EMIT_ROWS], y[EMIT_ROWS], x[EMIT_ROWS];
+#pragma unroll
+        for (int u = 0; u < EMIT_ROWS; ++u) {
+            const int j = min(j0 + u, nk - 1);   // the tail repeats the last row (loads only)
+            const int row = keep_idx[(size_t)b * max_keep + j];
+            s[u] = a[u] = y[u] = x[u] = 0;
+            if (SRC != 1) {
+                src[u] = pred + ((size_t)b * rows + row) * kdim;
+            } else {
+                s[u] = row >= g.rows_before[2] ? 2 : (row >= g.rows_before[1] ? 1 : 0);
+                const int lrow = row - g.rows_before[s[u]];
+                const int hw = g.h[s[u]] * g.w[s[u]];
+                a[u] = lrow / hw;
+                const int cell = lrow - a[u] * hw;
+                y[u] = cell / g.w[s[u]];
+                x[u] = cell - y[u] * g.w[s[u]];
+                src[u] = g.head[s[u]] + ((size_t)b * g.n_anchor * hw + lrow) * kdim;
             }
-            dst[k] = v;
+        }
+        for (int k0 = 0; k0 < kdim; k0 += 64) {
+            const int k = k0 + lane;
+            const bool live = k < kdim;
+            float v[EMIT_ROWS], p0[EMIT_ROWS], p1[EMIT_ROWS];
+#pragma unroll
+            for (int u = 0; u < EMIT_ROWS; ++u) {
+                v[u] = live ? src[u][k] : 0.0f;
+                // the box columns also need their partner column (centre <-> extent)
+                p0[u] = (k0 == 0 && SRC != 2 && k < 4) ? src[u][k < 2 ? k + 2 : k] : 0.0f;
+                p1[u] = (k0 == 0 && SRC >= 3 && k < 4) ? src[u][k < 2 ? k : k - 2] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < EMIT_ROWS; ++u) {
+                if (!live || j0 + u >= nk) continue;
+                float r = v[u];
+                if (SRC == 1) r = decode_value(g, s[u], k, a[u], y[u], x[u], r);
+                if (SRC >= 3 && k < 4) {
+                    // train_class.py:340,79,82: x_min = cx - w/2 ; w' = (x_min + w) - x_min
+                    const float wh = p0[u];
+                    const float lo = SRC == 3 ? p1[u] - wh / 2.0f : p1[u];
+                    r = k < 2 ? lo : (lo + wh) - lo;
+                } else if (SRC != 2 && k < 4) {
+                    // x_min = cx - w/2 ; cx' = x_min + w/2 ; scaled.  Same roundings as the reference.
+                    if (k < 2) {
+                        float wh = p0[u];
+                        if (SRC == 1) wh = decode_value(g, s[u], k + 2, a[u], y[u], x[u], wh);
+                        const float half = wh / 2.0f;
+                        r = ((r - half) + half) * (k == 0 ? xs : ys);
+                    } else {
+                        r = r * (k == 2 ? xs : ys);
+                    }
+                }
+                out[((size_t)b * max_keep + j0 + u) * kdim + k] = r;
+            }
         }
     }
 }
@@ -978,7 +1006,7 @@ int postprocess_impl(const float* pred, const DecodeGeom& g, int batch, int rows
     if (cand_count)
         if ((rc = (int)hipMemcpyAsync(cand_count, w.count, (size_t)batch * 4, hipMemcpyDeviceToDevice, st))) return rc;
     if (out_rows) {
-        const int gx = (max_keep + 3) / 4;
+        const int gx = (max_keep + 4 * EMIT_ROWS - 1) / (4 * EMIT_ROWS);
         emit_rows_kernel<SRC><<<dim3(gx > 512 ? 512 : gx, batch), 256, 0, st>>>(pred, g, rows, kdim, out_idx,
                                                                                    out_count, max_keep, scale_xy,
                                                                                    out_rows);
