@@ -435,10 +435,16 @@ __device__ __forceinline__ bool suppresses_corner(const float4 a, const float4 c
 }
 
 constexpr int MASK_WAVES = 4;
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+typedef float f32x8s __attribute__((ext_vector_type(8)));
 
 // Bare v_max_f32 / v_min_f32 (no NaN canonicalisation): only used where NaN cannot decide.
 __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// The same with the first operand in a scalar register (a value that is uniform over the wave).
+__device__ __forceinline__ float vmax_s(float s, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(s), "v"(b)); return r; }
+__device__ __forceinline__ float vmin_s(float s, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(s), "v"(b)); return r; }
 
 // w = 2*w + bit(lane) with the bit taken from a lane mask: one v_addc_co_u32 (carry-in = the mask).
 __device__ __forceinline__ uint32_t shift_in(uint32_t w, u64 lane_mask) {
@@ -475,22 +481,49 @@ __global__ void __launch_bounds__(256) iou_pairs_kernel(const float4* __restrict
     out[i] = inter / (p.z * p.w + c.z * c.w - inter);
 }
 
+// Column operands of the mask kernel's common path per sorted box: (x, y, x2, y2) in `colpk` and
+// k_lo*area in `colk`.  A wave reads the records of its column tile with
+// scalar loads: the values are uniform over the wave, so they cost neither vector registers nor
+// LDS bandwidth (64 lanes reading one LDS address still occupy the LDS pipe for a full pass).
+__device__ __forceinline__ void guard_factors(float thr, float& k_lo, float& k_hi) {
+    const double t_lo = (double)thr * (1.0 - 3.814697265625e-6), t_hi = (double)thr * (1.0 + 3.814697265625e-6);
+    k_lo = (float)(t_lo / (1.0 + t_lo));
+    k_hi = (float)(t_hi / (1.0 + t_hi));
+}
+
+__global__ void __launch_bounds__(256)
+pack_cols_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, int n_pad, float thr,
+                 float4* __restrict__ colpk, float* __restrict__ colk) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = count ? min(count[b], n_pad) : n_pad;
+    if (i >= n) return;
+    float k_lo, k_hi;
+    guard_factors(thr, k_lo, k_hi);
+    const float4 c = sbox[(size_t)b * n_pad + i];
+    const BoxEx e = box_ex(c);
+    colpk[(size_t)b * n_pad + i] = make_float4(c.x, c.y, e.x2, e.y2);
+    colk[(size_t)b * n_pad + i] = k_lo * e.area;
+}
+
 // Grid: (GX, GY, image).  The number of candidates is only known on the device, so a fixed, small
 // grid walks the tiles that exist: workgroup (bx, by) takes row tiles by, by+GY, ... of this chunk
 // and, for each, column-tile groups bx, bx+GX, ... at or right of the diagonal.
 // Wave w of a workgroup owns the 64x64 tile (row tile, column tile 4*group + w): lane i holds row
 // box i in registers, the 64 column boxes sit in the wave's LDS slice and are read as broadcasts.
 // Rows already suppressed by earlier chunks (bit set in `removed`) are skipped.
+// SCOL: the common path takes its column operands from `colpk` (pack_cols_kernel) with scalar loads.
+template <bool SCOL>
 __global__ void __launch_bounds__(64 * MASK_WAVES)
-iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, const u64* __restrict__ removed,
-                int n_pad, int row_begin, int row_end, float thr, int corner_rule, u64* __restrict__ mask,
-                size_t mask_stride_img) {
+iou_mask_kernel(const float4* __restrict__ sbox, const float4* __restrict__ colpk, const float* __restrict__ colk,
+                const int* __restrict__ count, const u64* __restrict__ removed, int n_pad, int row_begin, int row_end, float thr, int corner_rule,
+                u64* __restrict__ mask, size_t mask_stride_img) {
     __shared__ float4 cols[MASK_WAVES][64];
     __shared__ float4 colx[MASK_WAVES][64];
     __shared__ u64 col_special[MASK_WAVES];
     const bool thr_ok = thr > 1.0e-30f && thr < 1.0e30f;
-    const double t_lo = (double)thr * (1.0 - 3.814697265625e-6), t_hi = (double)thr * (1.0 + 3.814697265625e-6);
-    const float k_lo = (float)(t_lo / (1.0 + t_lo)), k_hi = (float)(t_hi / (1.0 + t_hi));
+    float k_lo, k_hi;
+    guard_factors(thr, k_lo, k_hi);
     const int b = blockIdx.z;
     const int n = count ? min(count[b], n_pad) : n_pad;
     const int words = n_pad >> 6;
@@ -501,7 +534,7 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
     const float4* boxes = sbox + (size_t)b * n_pad;
     for (int rt = (row_begin >> 6) + blockIdx.y; rt < rt_end; rt += gridDim.y)
     for (int grp = rt / MASK_WAVES + blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int ct = grp * MASK_WAVES + wave;  // global column tile
+    const int ct = __builtin_amdgcn_readfirstlane(grp * MASK_WAVES + wave);  // global column tile (wave-uniform)
     const bool active = (ct >= rt) && (ct < nwords);
     // every wave stages and reads only its own LDS slice: a wave-level barrier orders its accesses
     __builtin_amdgcn_wave_barrier();
@@ -551,19 +584,35 @@ iou_mask_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, 
                 for (int j0 = 0; j0 < 32; j0 += 8) {
                     u64 need[8];
                     float inter[8];
+                    f32x4s sc[SCOL ? 8 : 1];
+                    f32x8s sk;
+                    if (SCOL) {   // 8 columns: 8 x 16 bytes + 32 bytes, all wave-uniform addresses
+                        const size_t c0 = (size_t)b * n_pad + (size_t)ct * 64 + hh * 32 + j0;
+                        sk = *(const f32x8s*)(colk + c0);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) sc[u] = ((const f32x4s*)colpk)[c0 + u];
+                    }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int j = hh * 32 + j0 + u;
-                        const float4 c = cols[wave][j];
-                        const float4 e = colx[wave][j];
-                        const float x1 = vmax(a.x, c.x), y1 = vmax(a.y, c.y);
-                        const float x2 = vmin(ae.x2, e.x), y2 = vmin(ae.y2, e.y);
+                        float x1, y1, x2, y2, ez;
+                        if (SCOL) {
+                            x1 = vmax_s(sc[u][0], a.x); y1 = vmax_s(sc[u][1], a.y);
+                            x2 = vmin_s(sc[u][2], ae.x2); y2 = vmin_s(sc[u][3], ae.y2);
+                            ez = sk[u];
+                        } else {
+                            const float4 c = cols[wave][j];
+                            const float4 e = colx[wave][j];
+                            x1 = vmax(a.x, c.x); y1 = vmax(a.y, c.y);
+                            x2 = vmin(ae.x2, e.x); y2 = vmin(ae.y2, e.y);
+                            ez = e.z;
+                        }
                         // one clamp is enough for the keep test: with dx clamped, a negative dy makes the product
                         // non-positive and the (positive) threshold decides "keep" as it must
                         const float dy = y2 - y1;
                         const float prod = vmax(x2 - x1, 0.0f) * dy;
                         inter[u] = prod;
-                        need[u] = __ballot(!(prod < a_keep + e.z));
+                        need[u] = __ballot(!(prod < a_keep + ez));
                     }
                     if ((need[0] | need[1] | need[2] | need[3] | need[4] | need[5] | need[6] | need[7]) == 0ull) continue;
 #pragma unroll
@@ -898,6 +947,8 @@ struct Workspace {
     u64* keys;
     float4* rowbox;
     float4* sbox;
+    float4* colpk;   // column operands of the mask kernel (pack_cols_kernel)
+    float* colk;
     int* srow;
     u64* removed;
     u64* mask;
@@ -916,6 +967,8 @@ Workspace carve(char* base, int batch, int rows, int n_pad) {
     w.keys = (u64*)take((size_t)batch * n_pad * 8);
     w.rowbox = (float4*)take((size_t)batch * rows * 16);
     w.sbox = (float4*)take((size_t)batch * n_pad * 16);
+    w.colpk = (float4*)take((size_t)batch * n_pad * 16);
+    w.colk = (float*)take((size_t)batch * n_pad * 4);
     w.srow = (int*)take((size_t)batch * n_pad * 4);
     w.removed = (u64*)take((size_t)batch * (n_pad / 64) * 8);
     w.count = (int*)take((size_t)batch * 4);
@@ -946,12 +999,13 @@ int sort_keys(u64* keys, int batch, int n_pad, hipStream_t st) {
 int run_nms(const Workspace& w, const int* count, int batch, int n_pad, float iou_thr, int corner_rule, int* out_idx,
             int* out_count, int max_keep, hipStream_t st) {
     const int words = n_pad / 64;
+    pack_cols_kernel<<<dim3((n_pad + 255) / 256, batch), 256, 0, st>>>(w.sbox, count, n_pad, iou_thr, w.colpk, w.colk);
     for (int r0 = 0; r0 < n_pad; r0 += w.chunk_rows) {
         const int r1 = r0 + w.chunk_rows < n_pad ? r0 + w.chunk_rows : n_pad;
         const int gx = (words + MASK_WAVES - 1) / MASK_WAVES, gy = (r1 - r0) / 64;
         dim3 grid(gx < 8 ? gx : 8, gy < 32 ? gy : 32, batch);
-        iou_mask_kernel<<<grid, 64 * MASK_WAVES, 0, st>>>(w.sbox, count, w.removed, n_pad, r0, r1, iou_thr, corner_rule,
-                                                           w.mask, w.mask_stride_img);
+        iou_mask_kernel<true><<<grid, 64 * MASK_WAVES, 0, st>>>(w.sbox, w.colpk, w.colk, count, w.removed, n_pad, r0,
+                                                                 r1, iou_thr, corner_rule, w.mask, w.mask_stride_img);
         nms_scan_kernel<<<batch, SCAN_THREADS, (size_t)words * 8, st>>>(w.mask, w.mask_stride_img, count, w.srow,
                                                                         w.removed, n_pad, r0, r1, out_idx, out_count,
                                                                         max_keep);
@@ -1156,8 +1210,8 @@ int odamd_iou_mask(const float* boxes_xywh, int n, float iou_thr, uint64_t* mask
     const int words = n / 64;
     const int gx = (words + MASK_WAVES - 1) / MASK_WAVES;
     dim3 grid(gx < 8 ? gx : 8, words < 64 ? words : 64, 1);
-    iou_mask_kernel<<<grid, 64 * MASK_WAVES, 0, (hipStream_t)stream>>>((const float4*)boxes_xywh, nullptr, nullptr, n, 0,
-                                                                       n, iou_thr, 0, (u64*)mask, 0);
+    iou_mask_kernel<false><<<grid, 64 * MASK_WAVES, 0, (hipStream_t)stream>>>((const float4*)boxes_xywh, nullptr, nullptr,
+                                                                              nullptr, nullptr, n, 0, n, iou_thr, 0, (u64*)mask, 0);
     return (int)hipGetLastError();
 }
 

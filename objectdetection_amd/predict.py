@@ -134,8 +134,10 @@ class detect_pipeline:
         self.conf, self.iou = confidence_threshold, iou_threshold
         self.anchor = anchor if anchor is not None else model.decode.anchor_rel
         self.input_size = input_size if input_size is not None else model.decode.input_size
-        self.net_stream = torch.cuda.Stream()
-        self.post_stream = torch.cuda.Stream()
+        import os
+        pr = [int(v) for v in os.environ.get('ODAMD_PIPE_PRIO', '0,0').split(',')]
+        self.net_stream = torch.cuda.Stream(priority=pr[0])
+        self.post_stream = torch.cuda.Stream(priority=pr[1])
         self.slot = 0
         self.heads_free = [None, None]      # event: post-processing has finished reading the slot's heads
 
