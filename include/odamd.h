@@ -179,6 +179,14 @@ int odamd_conv_first_forward(const float* image, const float* w, const float* sc
                              void* y, int batch, int h, int w_in, int cout, int y_ld, int act, int dtype,
                              void* stream);
 
+/* First two layers in one launch, bf16 compute: cbs0 (3 -> 16, 3x3 stride 1) and cbs1 (16 -> 32, 3x3
+ * stride 2) of yolov7.forward (model/yolov7.py:114-115, preset 's'), eval-mode BatchNorm folded to
+ * scale/shift, SiLU after both.  The 16-channel activation between them stays on chip.
+ * w0: [16][ky][kx][3] float32; w1: [32][ky][kx][16] bf16; y: NHWC bf16 (B, Ho, Wo, y_ld), 32 channels. */
+int odamd_conv_first2_forward(const float* image, const float* w0, const float* scale0, const float* shift0,
+                              const void* w1, const float* scale1, const float* shift1, void* y, int batch, int h,
+                              int w_in, int y_ld, void* stream);
+
 /* MaxPool2d(2,2) (model/layer.py:125), three stride-1 max pools k=5,9,13 of one tensor
  * (model/layer.py:215-217) and nearest Upsample x2 (model/yolov7.py:32), all NHWC, each
  * able to write into a channel slice of a wider buffer. */

@@ -71,6 +71,8 @@ SIGNATURES = {
     'odamd_conv_forward': (c_int, [C.POINTER(ConvDesc), c_void_p]),
     'odamd_conv_first_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                          c_int, c_int, c_int, c_int, c_void_p]),
+    'odamd_conv_first2_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int, c_int, c_int, c_int, c_void_p]),
     'odamd_maxpool2_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'odamd_spp_pool3_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_int, c_void_p]),

@@ -699,6 +699,161 @@ conv_first_kernel(const float* __restrict__ img, const float* __restrict__ w, co
 }
 
 // ------------------------------------------------------------------------------------------
+// first + second layer in one launch (bf16): cbs0 (3 -> 16, 3x3 stride 1) feeding cbs1 (16 -> 32,
+// 3x3 stride 2).  The 16-channel full-resolution activation between them is the largest tensor of
+// the network (writing and re-reading it is about as much HBM traffic as the image and the second
+// layer's output together); here it only exists as a bf16 patch in LDS.
+// Workgroup (4 waves) = 4 x 32 output pixels of the second layer:
+//   A. image halo patch (11 x 67 pixels) -> LDS as bf16 (c0, c1, c2, 0) records
+//   B. first layer for the 9 x 65 pixels the second layer reads: three v_mfma_f32_32x32x16_bf16 per 32
+//      pixels (see first_weights_frag), affine + SiLU, bf16 into the LDS patch; pixels
+//      outside the image are the second layer's zero padding.  Even and odd columns are stored apart,
+//      so that the stride-2 reads of phase C walk consecutive 48-byte records (bank-conflict free).
+//   C. second layer: wave w owns output row w (32 pixels x 32 channels), nine v_mfma_f32_32x32x16_bf16
+//      (one per tap) with the weights held in registers; NHWC epilogue through LDS as everywhere.
+// ------------------------------------------------------------------------------------------
+namespace first2 {
+constexpr int TH = 4, TW = 32;   // TH = waves per workgroup
+constexpr int P1H = 2 * TH + 1, P1W = 2 * TW + 1;      // first-layer pixels needed: 9 x 65
+constexpr int P1EVEN = (P1W + 1) / 2;                   // even columns come first in a patch row
+constexpr int P0H = P1H + 2, P0W = P1W + 2, P0P = P0W + 2;   // image patch 11 x 67 (+2 zero columns)
+constexpr int PS = 48;                                  // bytes per first-layer pixel record (32 + 16 pad)
+constexpr int P1_BYTES = (P1H * P1W * PS + 255) & ~255;
+constexpr int STAGE_BYTES = TH * 32 * (128 + 16);       // epilogue slices of the waves (reuse the patch)
+constexpr int P0_BYTES = P0H * P0P * 8;                 // bf16 (c0, c1, c2, 0) per image pixel
+constexpr int LDS_BYTES = (P1_BYTES > STAGE_BYTES ? P1_BYTES : STAGE_BYTES) + P0_BYTES;
+}
+
+// First layer on the matrix cores from a bf16 (c0,c1,c2,0) image patch in LDS: per kernel row ky the
+// 3 taps x 4 channels of a pixel are 24 contiguous bytes, so K = (ky; kx, c) is three k-steps of
+// v_mfma_f32_32x32x16_bf16 whose B fragment is ONE 16-byte LDS read per lane (half h = 0: taps 0 and 1,
+// h = 1: tap 2 and four values that meet zero weights).  Rows 16..31 of A are zero.
+// Returns this lane's weight fragments; w0 is [16][ky][kx][3] float32.
+__device__ __forceinline__ void first_weights_frag(const float* __restrict__ w0, int r, int h, u32x4 (&wa)[3]) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // unconditional loads from clamped (always valid) addresses, so that all of them are in
+            // flight together; the padding positions are zeroed afterwards
+            const int kx = 2 * h + i / 4, c = i % 4;
+            const float t = w0[(r & 15) * 27 + (ky * 3 + (kx < 3 ? kx : 2)) * 3 + (c < 3 ? c : 2)];
+            v[i] = (r < 16 && kx < 3 && c < 3) ? t : 0.0f;
+        }
+        wa[ky] = u32x4{f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]), f32x2_to_bf16x2(v[4], v[5]),
+                       f32x2_to_bf16x2(v[6], v[7])};
+    }
+}
+
+__global__ void __launch_bounds__(64 * first2::TH)
+conv_first2_kernel(const float* __restrict__ img, const float* __restrict__ w0, const float* __restrict__ scale0,
+                   const float* __restrict__ shift0, const char* __restrict__ w1, const float* __restrict__ scale1,
+                   const float* __restrict__ shift1, char* __restrict__ y, int H, int W, int Ho, int Wo, int y_ld) {
+    using namespace first2;
+    constexpr int DT = ODAMD_DTYPE_BF16;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* p1 = lds;
+    char* p0 = lds + (P1_BYTES > STAGE_BYTES ? P1_BYTES : STAGE_BYTES);
+    const int b = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    // second-layer weights [32][3][3][16] bf16: lane (r, h) keeps its 8 input channels of every tap
+    u32x4 a[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) a[tap] = *(const u32x4*)(w1 + ((r * 9 + tap) * 16 + 8 * h) * 2);
+    u32x4 wa[3];
+    first_weights_frag(w0, r, h, wa);
+    float sc[8], sh[8];   // channels 4h+e (e < 4) and 8+4h+(e-4)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = (e < 4 ? 0 : 8) + 4 * h + (e & 3);
+        sc[e] = scale0[c];
+        sh[e] = shift0[c];
+    }
+
+    // ---- A: image patch, converted to bf16 once ------------------------------------------------
+    const int gy0 = 2 * oy0 - 2, gx0 = 2 * ox0 - 2;
+    // all loads of the wave's rows are issued before the first use (clamped, always valid addresses;
+    // positions outside the image are zeroed afterwards)
+    constexpr int NROW = (P0H + TH - 1) / TH;
+    float v[NROW][2][3];
+#pragma unroll
+    for (int i = 0; i < NROW; ++i) {
+        const int gy = min(max(gy0 + wave + i * TH, 0), H - 1);
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const int gx = min(max(gx0 + lane + 64 * part, 0), W - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                v[i][part][c] = (part == 0 || lane + 64 < P0P) ? img[(((size_t)b * 3 + c) * H + gy) * W + gx] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NROW; ++i) {
+        const int iy = wave + i * TH, gy = gy0 + iy;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const int ix = lane + 64 * part, gx = gx0 + ix;
+            if (iy >= P0H || ix >= P0P) continue;
+            const bool in = gy >= 0 && gy < H && ix < P0W && gx >= 0 && gx < W;
+            const uint2 pk = make_uint2(f32x2_to_bf16x2(v[i][part][0], v[i][part][1]), f32x2_to_bf16x2(v[i][part][2], 0.0f));
+            *(uint2*)(p0 + (iy * P0P + ix) * 8) = in ? pk : make_uint2(0u, 0u);
+        }
+    }
+    __syncthreads();
+    // ---- B: first layer into the bf16 patch -----------------------------------------------------
+    constexpr int NPIX = P1H * P1W, NGRP = (NPIX + 31) / 32;
+    for (int g = wave; g < NGRP; g += TH) {
+        const int q = g * 32 + r;
+        const int qq = q < NPIX ? q : NPIX - 1;
+        const int py = qq / P1W, px = qq - py * P1W;
+        const char* src = p0 + (py * P0P + px + 2 * h) * 8;
+        f32x16_t d;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) d[e] = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const uint2 lo = *(const uint2*)(src + ky * P0P * 8), hi = *(const uint2*)(src + ky * P0P * 8 + 8);
+            mma_step<DT>(d, wa[ky], u32x4{lo.x, lo.y, hi.x, hi.y});
+        }
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = silu<DT>(d[e] * sc[e] + sh[e]);
+        const int gy = gy0 + 1 + py, gx = gx0 + 1 + px;
+        const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        uint2 pk0, pk1;
+        pk0.x = inside ? f32x2_to_bf16x2(o[0], o[1]) : 0u;
+        pk0.y = inside ? f32x2_to_bf16x2(o[2], o[3]) : 0u;
+        pk1.x = inside ? f32x2_to_bf16x2(o[4], o[5]) : 0u;
+        pk1.y = inside ? f32x2_to_bf16x2(o[6], o[7]) : 0u;
+        if (q < NPIX) {
+            char* dst = p1 + (py * P1W + (px & 1) * P1EVEN + (px >> 1)) * PS + 8 * h;
+            *(uint2*)dst = pk0;
+            *(uint2*)(dst + 16) = pk1;
+        }
+    }
+    __syncthreads();
+    // ---- C: second layer ----------------------------------------------------------------------------
+    f32x16_t acc[1][1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.0f;
+    const int ty = wave;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        const u32x4 bb = *(const u32x4*)(p1 + ((2 * ty + ky) * P1W + (kx & 1) * P1EVEN + r + (kx >> 1)) * PS + 16 * h);
+        mma_step<DT>(acc[0][0], a[tap], bb);
+    }
+    __syncthreads();   // every wave is done reading the patch: its memory becomes the epilogue slices
+    const int oy = oy0 + ty, ox = ox0 + r;
+    int opix[1] = {(oy < Ho && ox < Wo) ? oy * Wo + ox : -1};
+    nhwc_epilogue<DT, 1, 1>(acc, opix, lds + wave * (32 * (128 + 16)), lane, 0, (size_t)b * Ho * Wo, scale1, shift1, 32, y,
+                            y_ld, 1, 0);
+}
+
+// ------------------------------------------------------------------------------------------
 // pools / upsample / layout converters: one thread per (pixel, 16-byte channel vector)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint4 neg_inf16(int dt) {
@@ -1048,6 +1203,21 @@ int odamd_conv_first_forward(const float* image, const float* w, const float* sc
             image, w, scale, shift, (char*)y, h, w_in, cout, y_ld, act);
     else
         conv_first_kernel<ODAMD_DTYPE_BF16><<<grid, 256, lds, (hipStream_t)stream>>>(image, w, scale, shift, (char*)y, h, w_in, cout, y_ld, act);
+    return (int)hipGetLastError();
+}
+
+int odamd_conv_first2_forward(const float* image, const float* w0, const float* scale0, const float* shift0,
+                              const void* w1, const float* scale1, const float* shift1, void* y, int batch, int h,
+                              int w_in, int y_ld, void* stream) {
+    if (!image || !w0 || !scale0 || !shift0 || !w1 || !scale1 || !shift1 || !y || batch < 1 || h < 2 || w_in < 2)
+        return ODAMD_E_ARG;
+    if (y_ld < 32) return ODAMD_E_SHAPE;
+    if (((uintptr_t)y & 15) || ((uintptr_t)w1 & 15) || (y_ld * 2) % 16) return ODAMD_E_ALIGN;
+    const int ho = (h - 1) / 2 + 1, wo = (w_in - 1) / 2 + 1;
+    dim3 grid((wo + first2::TW - 1) / first2::TW, (ho + first2::TH - 1) / first2::TH, batch);
+    static_assert(first2::LDS_BYTES <= 64 * 1024, "fits the default LDS limit of a workgroup");
+    conv_first2_kernel<<<grid, 64 * first2::TH, first2::LDS_BYTES, (hipStream_t)stream>>>(
+        image, w0, scale0, shift0, (const char*)w1, scale1, shift1, (char*)y, h, w_in, ho, wo, y_ld);
     return (int)hipGetLastError();
 }
 

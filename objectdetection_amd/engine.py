@@ -23,6 +23,7 @@ from . import _lib
 from ._lib import lib, check
 
 F32, BF16 = 0, 1
+FUSE_FIRST2 = True     # bf16 plans run cbs0 + cbs1 as one launch when the widths are 16 and 32
 _TORCH_DT = {0: torch.float32, 1: torch.bfloat16}
 CH_ALIGN = 16            # channel granule of buffer slices in bf16 plans (f32 plans use 8)
 
@@ -174,8 +175,7 @@ class Plan:
     def __init__(self, builder, finish=None):
         self.b = builder
         dt = _TORCH_DT[builder.dtype]
-        self.bufs = [torch.zeros((builder.batch, h, w, c), dtype=dt, device=builder.device)
-                     for c, h, w in builder.buffers]
+        self.bufs = None
         self.es = 2 if builder.dtype == BF16 else 4
         self.launches = []
         self.meta = {}          # launch index -> {kernel, flops, bytes, shape} (algorithmic work, for profiling)
@@ -184,6 +184,13 @@ class Plan:
         self.outputs = {}
         self.finish = finish
         self._fuse_sibling_convs()
+        used = set()
+        for op in builder.ops:      # buffers no launch touches any more (fused away) are not allocated
+            for a in [op.get('x'), op.get('y')] + list(op.get('ys', [])):
+                if a is not None and not (op['kind'] == 'first2' and a is op.get('x')):
+                    used.add(a.buf)
+        self.bufs = [torch.zeros((builder.batch, h, w, c) if i in used else (0, h, w, c), dtype=dt, device=builder.device)
+                     for i, (c, h, w) in enumerate(builder.buffers)]
         self._build()
 
     def _fuse_sibling_convs(self):
@@ -207,8 +214,24 @@ class Plan:
             else:
                 out.append(a)
                 i += 1
+        out = self._fuse_first_two(out)
         self.b.ops = out
-        self.b.convs = [op for op in out if op['kind'] in ('conv', 'head', 'first')]
+        self.b.convs = [op for op in out if op['kind'] in ('conv', 'head', 'first', 'first2')]
+
+    def _fuse_first_two(self, ops):
+        """cbs0 (3 -> 16, stride 1) followed by cbs1 (16 -> 32, 3x3 stride 2) in bf16 becomes ONE launch
+        (odamd_conv_first2_forward): the full-resolution 16-channel activation between them, the largest
+        tensor of the network, is never written to HBM."""
+        if not FUSE_FIRST2 or self.b.dtype != BF16 or len(ops) < 2:
+            return ops
+        a, b = ops[0], ops[1]
+        if not (a['kind'] == 'first' and b['kind'] == 'conv' and b['x'] is a['y'] and 'mods' not in b
+                and b['k'] == 3 and b['s'] == 2 and not b['pool'] and a['mod'].conv.out_channels == 16
+                and b['mod'].conv.out_channels == 32 and len(b['y'].segments) == 1):
+            return ops
+        if any(op.get('x') is a['y'] or op.get('x') is not None and op['x'].buf == a['y'].buf for op in ops[2:]):
+            return ops
+        return [dict(kind='first2', mod=b['mod'], mod0=a['mod'], x=a['y'], y=b['y'])] + ops[2:]
 
     # ---- addressing ----------------------------------------------------------------------
     def _ptr(self, act):
@@ -222,7 +245,7 @@ class Plan:
     def _versions(self):
         v = 0
         for op in self.b.convs:
-            for m in op.get('mods', [op['mod']]):
+            for m in op.get('mods', [op['mod']]) + ([op['mod0']] if 'mod0' in op else []):
                 if op['kind'] == 'head':
                     v += m.output.weight._version + m.output.bias._version
                 else:
@@ -242,6 +265,16 @@ class Plan:
                     w = _pack_weight(m.output.weight, op['x'], self.b.dtype)
                     op['w'].copy_(w.view(-1))
                     op['shift'].copy_(m.output.bias.detach().float())
+                elif op['kind'] == 'first2':
+                    m0 = op['mod0']
+                    op['w0'].copy_(m0.conv.weight.detach().float().permute(0, 2, 3, 1).reshape(-1))
+                    sc, sh = _fold_bn(m0.bn)
+                    op['scale0'].copy_(sc)
+                    op['shift0'].copy_(sh)
+                    op['w'].copy_(_pack_weight(m.conv.weight, op['x'], self.b.dtype).view(-1))
+                    sc, sh = _fold_bn(m.bn)
+                    op['scale'].copy_(sc)
+                    op['shift'].copy_(sh)
                 elif op['kind'] == 'first':
                     op['w'].copy_(m.conv.weight.detach().float().permute(0, 2, 3, 1).reshape(-1))
                     sc, sh = _fold_bn(m.bn)
@@ -301,6 +334,19 @@ class Plan:
                 self.launches.append((lib.odamd_conv_first_forward,
                                       [0, op['w'].data_ptr(), op['scale'].data_ptr(), op['shift'].data_ptr(),
                                        self._ptr(y), B, y.h, y.w, cout, self._ld(y), 1, b.dtype], 'first', 0))
+            elif kind == 'first2':
+                y, x = op['y'], op['x']
+                op['w0'] = torch.empty(16 * 27, dtype=torch.float32, device=dev)
+                op['w'] = torch.empty(32 * 9 * 16, dtype=dt, device=dev)
+                for n, c in (('scale0', 16), ('shift0', 16), ('scale', 32), ('shift', 32)):
+                    op[n] = torch.empty(c, dtype=torch.float32, device=dev)
+                self.launches.append((lib.odamd_conv_first2_forward,
+                                      [0, op['w0'].data_ptr(), op['scale0'].data_ptr(), op['shift0'].data_ptr(),
+                                       op['w'].data_ptr(), op['scale'].data_ptr(), op['shift'].data_ptr(),
+                                       self._ptr(y), B, x.h, x.w, self._ld(y)], 'first2', 0))
+                self.meta[len(self.launches) - 1] = dict(
+                    kernel='first2', flops=2.0 * B * (x.h * x.w * 16 * 27 + y.h * y.w * 32 * 9 * 16),
+                    bytes=float(B * (x.h * x.w * 3 * 4 + y.h * y.w * 32 * self.es)), shape='%dx%d 3->16->32' % (x.h, x.w))
             elif kind == 'maxpool2':
                 x, y = op['x'], op['y']
                 self.launches.append((lib.odamd_maxpool2_forward,

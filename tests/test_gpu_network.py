@@ -204,7 +204,7 @@ def test_every_layer_against_oracle_taps(od, dtype, preset, size):
         engine.set_compute_dtype(None)
     checked, worst = 0, 0.0
     for op in plan.b.ops:
-        if op['kind'] not in ('conv', 'first'):
+        if op['kind'] not in ('conv', 'first', 'first2'):
             continue
         y = op['y']
         buf = plan.bufs[y.buf][..., y.c0:y.c0 + y.cphys].float().cpu()
@@ -218,6 +218,47 @@ def test_every_layer_against_oracle_taps(od, dtype, preset, size):
             assert err < TOL[dtype], (names[m], err)
             checked += 1
     assert checked >= {'s': 55, 'm': 60, 'l': 70}[preset], checked
+
+
+@pytest.mark.parametrize('size', [64, 96, 160])
+def test_fused_first_two_layers(od, size):
+    """bf16 plans run cbs0 + cbs1 (model/yolov7.py:114-115) as one launch; against the two separate
+    launches (same bf16 operands, different accumulation order inside the matrix cores) the result may
+    differ by a bf16 rounding of the intermediate here and there, never more; sizes with whole and
+    ragged output tiles, image borders included."""
+    engine, layer, ymod = od
+    args = patterns.default_args(input_size=size, output_class=3)
+    torch.manual_seed(5)
+    net = ymod.yolov7(args)
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.bias.shape, generator=g) * 0.5 + 0.25)
+    net = net.cuda().eval()
+    x = torch.rand(3, 3, size, size, generator=g).cuda()
+    outs, kinds = [], []
+    engine.set_compute_dtype('bf16')
+    try:
+        for fuse in (True, False):
+            engine.FUSE_FIRST2 = fuse
+            net._plans.clear()          # plans are cached per (shape, dtype): lower again
+            net(x)
+            plan = net._plan(x)
+            kinds.append([op['kind'] for op in plan.b.ops[:2]])
+            op = next(o for o in plan.b.ops if o['kind'] in ('first2', 'conv'))
+            y = op['y']
+            outs.append(plan.bufs[y.buf][..., y.c0:y.c0 + 32].clone())
+    finally:
+        engine.FUSE_FIRST2 = True
+        engine.set_compute_dtype(None)
+    assert kinds[0][0] == 'first2' and kinds[1] == ['first', 'conv'], kinds
+    a, b = outs[0].float(), outs[1].float()
+    assert (a - b).abs().max() <= 2.0 ** -7 * b.abs().max()
+    assert (a != b).float().mean() < 0.02
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
@@ -258,7 +299,7 @@ def test_pruned_config_network(od, dtype):
     assert rel_err(got[..., 4:], ref[..., 4:]) < TOL[dtype]
     checked = 0
     for op in plan.b.ops:
-        if op['kind'] not in ('conv', 'first'):
+        if op['kind'] not in ('conv', 'first', 'first2'):
             continue
         y = op['y']
         buf = plan.bufs[y.buf][..., y.c0:y.c0 + y.cphys].float().cpu()
