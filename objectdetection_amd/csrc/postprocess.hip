@@ -23,7 +23,10 @@ namespace {
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ float sigmoid_f32(float x) { return 1.0f / (1.0f + expf(-x)); }
+// 1 / (1 + e^-x): the library exponential and the hardware reciprocal (1 ulp; the IEEE division
+// sequence is ten more vector instructions per value and these kernels are issue-bound without it).
+// Every kernel of this file uses this one form, so the fused and the materialised paths agree bit for bit.
+__device__ __forceinline__ float sigmoid_f32(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
 
 // ------------------------------------------------------------------------------------------
 // decode
@@ -46,6 +49,17 @@ __device__ __forceinline__ float decode_value(const DecodeGeom& g, int s, int k,
         return (4.0f * (t * t)) * g.anchor[s][a][k - 2];
     }
     return g.deploy ? sigmoid_f32(raw) : raw;
+}
+
+// The same element from t = sigmoid_f32(raw) evaluated by the caller (once, for all lanes alike).
+__device__ __forceinline__ float decode_from_sigmoid(const DecodeGeom& g, int s, int k, int a, int y, int x, float raw,
+                                                     float t) {
+    if (k < 4) {
+        if (k == 0) return (2.0f * t - 0.5f + (float)x) * g.stride[s];
+        if (k == 1) return (2.0f * t - 0.5f + (float)y) * g.stride[s];
+        return (4.0f * (t * t)) * g.anchor[s][a][k - 2];
+    }
+    return g.deploy ? t : raw;
 }
 
 __global__ void __launch_bounds__(256) decode_kernel(DecodeGeom g, float* __restrict__ out) {
@@ -784,7 +798,7 @@ nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int*
 // the row's (scale, anchor, cell) is wave-uniform, lanes walk the K columns.  A wave takes
 // EMIT_ROWS consecutive kept rows per trip and issues all their loads before the first use, so
 // that enough reads are in flight to cover the latency of HBM.
-constexpr int EMIT_ROWS = 4;
+constexpr int EMIT_ROWS = 8;
 
 template <int SRC>
 __global__ void __launch_bounds__(256)
@@ -833,7 +847,7 @@ emit_rows_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdi
             for (int u = 0; u < EMIT_ROWS; ++u) {
                 if (!live || j0 + u >= nk) continue;
                 float r = v[u];
-                if (SRC == 1) r = decode_value(g, s[u], k, a[u], y[u], x[u], r);
+                if (SRC == 1) r = decode_from_sigmoid(g, s[u], k, a[u], y[u], x[u], r, sigmoid_f32(r));
                 if (SRC >= 3 && k < 4) {
                     // train_class.py:340,79,82: x_min = cx - w/2 ; w' = (x_min + w) - x_min
                     const float wh = p0[u];
@@ -852,6 +866,86 @@ emit_rows_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdi
                 }
                 out[((size_t)b * max_keep + j0 + u) * kdim + k] = r;
             }
+        }
+    }
+}
+
+// emit_rows_kernel<1> (rows decoded from the raw heads) in a leaner form, used when every grid is
+// narrower than 4096 cells: the row's (scale, anchor, cell) is worked out once per row with scalar
+// values (anchor by comparisons, the cell split by a float reciprocal), the class columns are a plain
+// elementwise pass (one sigmoid per element, no divergence) and the 4 box columns of the wave's 4 rows
+// are handled together by 16 lanes.  Same arithmetic per element as decode_kernel + emit_rows_kernel<0>.
+struct EmitGeom { float inv_w[3]; };
+
+__global__ void __launch_bounds__(256)
+emit_heads_kernel(DecodeGeom g, EmitGeom eg, int kdim, const int* __restrict__ keep_idx, const int* __restrict__ keep_count,
+                  int max_keep, const float* __restrict__ scale_xy, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int nk = min(keep_count[b], max_keep);
+    const float xs = scale_xy ? scale_xy[2 * b] : 1.0f;
+    const float ys = scale_xy ? scale_xy[2 * b + 1] : 1.0f;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    for (int j0 = wave * EMIT_ROWS; j0 < nk; j0 += gridDim.x * 4 * EMIT_ROWS) {
+        const float* src[EMIT_ROWS];
+        float stride[EMIT_ROWS], aw[EMIT_ROWS], ah[EMIT_ROWS], fx[EMIT_ROWS], fy[EMIT_ROWS];
+#pragma unroll
+        for (int u = 0; u < EMIT_ROWS; ++u) {
+            const int j = min(j0 + u, nk - 1);   // the tail repeats the last row (loads only)
+            const int row = __builtin_amdgcn_readfirstlane(keep_idx[(size_t)b * max_keep + j]);
+            const int s = row >= g.rows_before[2] ? 2 : (row >= g.rows_before[1] ? 1 : 0);
+            const int lrow = row - g.rows_before[s];
+            const int hw = g.h[s] * g.w[s];
+            const int a = (lrow >= hw) + (lrow >= 2 * hw) + (lrow >= 3 * hw);
+            const int cell = lrow - a * hw;
+            // floor(cell / w): (cell + 0.5) / w stays 0.5 / w away from an integer, far more than the
+            // rounding error of the float product for cell < 2^21 and w < 2^12
+            const int y = (int)(((float)cell + 0.5f) * eg.inv_w[s]);
+            const int x = cell - y * g.w[s];
+            src[u] = g.head[s] + ((size_t)b * g.n_anchor * hw + lrow) * kdim;
+            stride[u] = g.stride[s];
+            aw[u] = g.anchor[s][a][0];
+            ah[u] = g.anchor[s][a][1];
+            fx[u] = (float)x;
+            fy[u] = (float)y;
+        }
+        // class columns (and objectness): elementwise
+        for (int k0 = 0; k0 < kdim; k0 += 64) {
+            const int k = k0 + lane;
+            const bool live = k >= 4 && k < kdim;
+            float v[EMIT_ROWS];
+#pragma unroll
+            for (int u = 0; u < EMIT_ROWS; ++u) v[u] = live ? src[u][k] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < EMIT_ROWS; ++u)
+                if (live && j0 + u < nk)
+                    out[((size_t)b * max_keep + j0 + u) * kdim + k] = g.deploy ? sigmoid_f32(v[u]) : v[u];
+        }
+        // box columns: lane l < 4 * EMIT_ROWS -> (row l / 4, column l % 4)
+        if (lane < 4 * EMIT_ROWS) {
+            const int u = lane >> 2, k = lane & 3;
+            const float* sp = src[0];
+            float st = stride[0], an = k == 2 ? aw[0] : ah[0], gc = k == 0 ? fx[0] : fy[0];
+#pragma unroll
+            for (int q = 1; q < EMIT_ROWS; ++q)
+                if (u == q) {
+                    sp = src[q];
+                    st = stride[q];
+                    an = k == 2 ? aw[q] : ah[q];
+                    gc = k == 0 ? fx[q] : fy[q];
+                }
+            const float t = sigmoid_f32(sp[k]);
+            // decode_value: (2t - 0.5 + cell) * stride for the centre, 4 t^2 * anchor for the extent
+            const float val = k < 2 ? (2.0f * t - 0.5f + gc) * st : (4.0f * (t * t)) * an;
+            const float wh = __shfl_down(val, 2);      // the extent that belongs to this centre column
+            float r;
+            if (k < 2) {   // x_min = cx - w/2 ; cx' = x_min + w/2 ; scaled.  Same roundings as the reference.
+                const float half = wh / 2.0f;
+                r = ((val - half) + half) * (k == 0 ? xs : ys);
+            } else {
+                r = val * (k == 2 ? xs : ys);
+            }
+            if (j0 + u < nk) out[((size_t)b * max_keep + j0 + u) * kdim + k] = r;
         }
     }
 }
@@ -1061,9 +1155,19 @@ int postprocess_impl(const float* pred, const DecodeGeom& g, int batch, int rows
         if ((rc = (int)hipMemcpyAsync(cand_count, w.count, (size_t)batch * 4, hipMemcpyDeviceToDevice, st))) return rc;
     if (out_rows) {
         const int gx = (max_keep + 4 * EMIT_ROWS - 1) / (4 * EMIT_ROWS);
-        emit_rows_kernel<SRC><<<dim3(gx > 512 ? 512 : gx, batch), 256, 0, st>>>(pred, g, rows, kdim, out_idx,
-                                                                                   out_count, max_keep, scale_xy,
-                                                                                   out_rows);
+        bool lean = SRC == 1;
+        EmitGeom eg = {};
+        for (int s = 0; s < 3 && lean; ++s) {
+            lean = g.w[s] < 4096 && (long long)g.h[s] * g.w[s] < (1 << 21);
+            eg.inv_w[s] = 1.0f / (float)g.w[s];
+        }
+        if (lean)
+            emit_heads_kernel<<<dim3(gx > 512 ? 512 : gx, batch), 256, 0, st>>>(g, eg, kdim, out_idx, out_count, max_keep,
+                                                                               scale_xy, out_rows);
+        else
+            emit_rows_kernel<SRC><<<dim3(gx > 512 ? 512 : gx, batch), 256, 0, st>>>(pred, g, rows, kdim, out_idx,
+                                                                                       out_count, max_keep, scale_xy,
+                                                                                       out_rows);
     }
     return (int)hipGetLastError();
 }
