@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "common.h"
+#include <stdlib.h>
 #include "odamd.h"
 
 namespace {
@@ -683,6 +684,202 @@ iou_mask_kernel(const float4* __restrict__ sbox, const float4* __restrict__ colp
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// IoU mask with area windows.  A pair can only reach the threshold when the two areas are within
+// a factor (1 + thr) / thr of each other, and the cheap keep test of iou_mask_kernel already proves
+// it: inter <= min(ea_row, ea_col) (ea = product of the rounded extents, see below), so
+//     ea_col < k_lo * area_row            or            ea_row < k_lo * area_col
+// implies inter < k_lo * area_row + k_lo * area_col, the "surely survives" decision.  To make that
+// usable for whole waves, the rows of a wave are chosen by size: within blocks of AREA_BLOCK sorted
+// positions the rows are listed by ascending area (area_order_kernel); a wave takes 64 consecutive
+// entries, i.e. rows of similar area from a 1024-wide score window, and for every column tile a ballot
+// over the column boxes keeps only the columns that some row of the wave could meet at the threshold and
+// packs them into the wave's LDS slice.  The surviving columns (about half on mixed-size candidates) run
+// through the same common-case test as in iou_mask_kernel, eight at a time; everything else (irregular boxes, second look, exact
+// arithmetic) is unchanged, and so are the bits written: the scan kernel cannot tell the difference.
+// The price: the strict upper triangle is only exploited per block (column tiles before the rows' block
+// are skipped, the block's own 16 tiles are computed for all rows and masked per lane).
+//   inter <= ea: dx = fl(min(ax2, cx2) - max(ax, cx)) <= fl(ax2 - ax) = ew by monotone rounding, same for dy,
+//   and for dx, dy > 0 fl(dx * dy) <= fl(ew * eh); with dx <= 0 or dy <= 0 the product is <= 0.
+// ------------------------------------------------------------------------------------------
+constexpr int AREA_BLOCK = 1024;
+
+__global__ void __launch_bounds__(256)
+area_order_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, int n_pad, int* __restrict__ perm) {
+    __shared__ u64 s[AREA_BLOCK];
+    const int b = blockIdx.y, base = blockIdx.x * AREA_BLOCK;
+    const int n = count ? min(count[b], n_pad) : n_pad;
+    for (int t = threadIdx.x; t < AREA_BLOCK; t += 256) {
+        const int gi = base + t;
+        u64 key = ~0ull;
+        if (gi < n) {
+            const BoxEx e = box_ex(sbox[(size_t)b * n_pad + gi]);
+            // positive floats order like their bit patterns; irregular boxes go last
+            const uint32_t ab = e.special != 0.0f ? 0x7F800000u : __float_as_uint(e.area);
+            key = ((u64)ab << 32) | (uint32_t)gi;
+        }
+        s[t] = key;
+    }
+    __syncthreads();
+    if (base < n) {
+        for (int k = 2; k <= AREA_BLOCK; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = threadIdx.x; t < AREA_BLOCK / 2; t += 256) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int q = i | j;
+                    const u64 x = s[i], y = s[q];
+                    if ((x > y) == ((i & k) == 0)) { s[i] = y; s[q] = x; }
+                }
+                __syncthreads();
+            }
+    }
+    for (int t = threadIdx.x; t < AREA_BLOCK; t += 256)
+        perm[(size_t)b * n_pad + base + t] = s[t] == ~0ull ? -1 : (int)(uint32_t)s[t];
+}
+
+__global__ void __launch_bounds__(64 * MASK_WAVES)
+iou_mask_win_kernel(const float4* __restrict__ sbox, const int* __restrict__ perm, const int* __restrict__ count, const u64* __restrict__ removed,
+                    int n_pad, int row_begin, int row_end, float thr, int corner_rule, u64* __restrict__ mask,
+                    size_t mask_stride_img) {
+    __shared__ float4 cols[MASK_WAVES][64];
+    __shared__ float4 colx[MASK_WAVES][64];
+    // the surviving columns of the wave's tile, packed: (x, y, x2, y2), k_lo * area, original column
+    __shared__ float4 pk_box[MASK_WAVES][72];
+    __shared__ float pk_k[MASK_WAVES][72];
+    __shared__ int pk_j[MASK_WAVES][72];
+    const bool thr_ok = thr > 1.0e-30f && thr < 1.0e30f;
+    float k_lo, k_hi;
+    guard_factors(thr, k_lo, k_hi);
+    const int b = blockIdx.z;
+    const int n = min(count[b], n_pad);
+    const int words = n_pad >> 6;
+    const int nwords = (n + 63) >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rg_end = (min(row_end, n) + 63) >> 6;
+    const int ngroups = (nwords + MASK_WAVES - 1) / MASK_WAVES;
+    const float4* boxes = sbox + (size_t)b * n_pad;
+    for (int rg = (row_begin >> 6) + blockIdx.y; rg < rg_end; rg += gridDim.y) {
+        const int tile0 = (rg * 64 / AREA_BLOCK) * (AREA_BLOCK / 64);   // first column tile of the rows' block
+        const int i = perm[(size_t)b * n_pad + rg * 64 + lane];         // sorted position of this lane's row, or -1
+        bool live = i >= 0;
+        if (live) live = !((removed[(size_t)b * words + (i >> 6)] >> (i & 63)) & 1ull);
+        const u64 live_mask = __ballot(live);
+        const float4 a = live ? boxes[i] : make_float4(0, 0, 0, 0);
+        const BoxEx ae = box_ex(a);
+        const float a_lo = k_lo * ae.area, a_hi = k_hi * ae.area;
+        const u64 row_special = __ballot(ae.special != 0.0f || !live) | (thr_ok ? 0ull : ~0ull);
+        const bool rows_regular = __ballot(live && ae.special != 0.0f) == 0ull && thr_ok;
+        // the wave's window: smallest row threshold share, largest row "effective area"
+        float wmin = live ? a_lo : __builtin_inff();
+        float wmax = live ? (ae.x2 - a.x) * (ae.y2 - a.y) : -__builtin_inff();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            wmin = fminf(wmin, __shfl_xor(wmin, o));
+            wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+        }
+        for (int grp = tile0 / MASK_WAVES + blockIdx.x; grp < ngroups; grp += gridDim.x) {
+            const int ct = __builtin_amdgcn_readfirstlane(grp * MASK_WAVES + wave);   // column tile (wave-uniform)
+            if (ct >= nwords) continue;
+            // every wave stages and reads only its own LDS slice: a wave-level barrier orders its accesses
+            __builtin_amdgcn_wave_barrier();
+            const bool cvalid = ct * 64 + lane < n;
+            const float4 c = cvalid ? boxes[ct * 64 + lane] : make_float4(0, 0, 0, 0);
+            const BoxEx e = box_ex(c);
+            cols[wave][lane] = c;
+            colx[wave][lane] = make_float4(e.x2, e.y2, k_lo * e.area, k_hi * e.area);
+            const u64 cspec = __ballot(e.special != 0.0f);
+            // columns some row of this wave could meet at the threshold (negated tests: NaN keeps the column)
+            const bool keep_col = cvalid && !((e.x2 - c.x) * (e.y2 - c.y) < wmin) && !(wmax < k_lo * e.area);
+            const u64 compat = __ballot(keep_col);
+            const int ncompat = __popcll(compat);
+            if (keep_col) {
+                const int pos = __popcll(compat & ((1ull << lane) - 1ull));
+                pk_box[wave][pos] = make_float4(c.x, c.y, e.x2, e.y2);
+                pk_k[wave][pos] = k_lo * e.area;
+                pk_j[wave][pos] = lane;
+            }
+            if (lane < 8) {   // a short last batch meets records that can never ask for the second look
+                pk_box[wave][ncompat + lane] = make_float4(0, 0, 0, 0);
+                pk_k[wave][ncompat + lane] = __builtin_inff();
+                pk_j[wave][ncompat + lane] = 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            u64 word = 0;
+            if (live_mask) {
+                uint32_t half[2] = {0u, 0u};
+                if (rows_regular && cspec == 0ull) {
+                    // Common case, every box of the tile regular (all 64 columns exist: a missing one is irregular).
+                    const float a_keep = live ? a_lo : __builtin_inff();   // idle lanes never ask for the second look
+#pragma unroll 1
+                    for (int q0 = 0; q0 < ncompat; q0 += 8) {   // eight surviving columns per branch
+                        u64 need[8];
+                        float inter[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const float4 cb = pk_box[wave][q0 + u];
+                            const float x1 = vmax(a.x, cb.x), y1 = vmax(a.y, cb.y);
+                            const float x2 = vmin(ae.x2, cb.z), y2 = vmin(ae.y2, cb.w);
+                            const float dy = y2 - y1;
+                            const float prod = vmax(x2 - x1, 0.0f) * dy;
+                            inter[u] = prod;
+                            need[u] = __ballot(!(prod < a_keep + pk_k[wave][q0 + u]));
+                        }
+                        if ((need[0] | need[1] | need[2] | need[3] | need[4] | need[5] | need[6] | need[7]) == 0ull) continue;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (need[u] == 0ull) continue;
+                            const int j = __builtin_amdgcn_readfirstlane(pk_j[wave][q0 + u]);
+                            const float4 cc = cols[wave][j];
+                            // need => product >= threshold > 0 => dy > 0 (dx > 0): the product is the intersection
+                            u64 sup = __ballot(inter[u] > a_hi + colx[wave][j].w) & need[u];
+                            const u64 amb = need[u] & ~sup;                 // inside the guard band: exact arithmetic
+                            if (amb) {
+                                const bool mine = (amb >> lane) & 1ull;
+                                sup |= __ballot(mine && (corner_rule ? suppresses_corner(a, cc, thr) : suppresses(a, cc, thr)));
+                            }
+                            const uint32_t bit = (uint32_t)((sup >> lane) & 1ull);
+                            if (j < 32) half[0] |= bit << j;
+                            else half[1] |= bit << (j - 32);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int hh = 1; hh >= 0; --hh) {
+                        uint32_t w32 = 0;
+#pragma unroll 8
+                        for (int jq = 31; jq >= 0; --jq) {      // descending: the shift-in below builds bit jq last-in-lowest
+                            const int j = hh * 32 + jq;
+                            const float4 cc = cols[wave][j];
+                            const float4 ex = colx[wave][j];
+                            const float x1 = vmax(a.x, cc.x), y1 = vmax(a.y, cc.y);
+                            const float x2 = vmin(ae.x2, ex.x), y2 = vmin(ae.y2, ex.y);
+                            const float inter = vmax(x2 - x1, 0.0f) * vmax(y2 - y1, 0.0f);
+                            const u64 keep_sure = __ballot(inter < a_lo + ex.z);
+                            u64 sup = __ballot(inter > a_hi + ex.w);
+                            u64 amb = (~(keep_sure | sup) | row_special | (((cspec >> j) & 1ull) ? ~0ull : 0ull)) & live_mask;
+                            if (amb) {
+                                const bool mine = (amb >> lane) & 1ull;
+                                const u64 exact = __ballot(mine && (corner_rule ? suppresses_corner(a, cc, thr) : suppresses(a, cc, thr)));
+                                sup = (sup & ~amb) | exact;
+                            }
+                            w32 = shift_in(w32, sup);
+                        }
+                        half[hh] = w32;
+                    }
+                }
+                word = ((u64)half[1] << 32) | half[0];
+                const int ncol = n - ct * 64;                                     // valid columns of this tile
+                if (ncol < 64) word &= (1ull << ncol) - 1ull;
+                const int lim = i - ct * 64;                                      // strictly later boxes only
+                if (lim >= 63) word = 0;
+                else if (lim >= 0) word &= ~((2ull << lim) - 1ull);
+                if (!live) word = 0;
+            }
+            if (i >= 0) mask[(size_t)b * mask_stride_img + (size_t)(i - row_begin) * words + ct] = word;
+        }
+    }
+}
+
 constexpr int SCAN_THREADS = 256;
 
 // One workgroup per image.  `removed` (n_pad bits) lives in LDS for the chunk and in global
@@ -1044,6 +1241,7 @@ struct Workspace {
     float4* colpk;   // column operands of the mask kernel (pack_cols_kernel)
     float* colk;
     int* srow;
+    int* perm;       // row order of the windowed mask kernel (area_order_kernel)
     u64* removed;
     u64* mask;
     int* count;
@@ -1064,6 +1262,7 @@ Workspace carve(char* base, int batch, int rows, int n_pad) {
     w.colpk = (float4*)take((size_t)batch * n_pad * 16);
     w.colk = (float*)take((size_t)batch * n_pad * 4);
     w.srow = (int*)take((size_t)batch * n_pad * 4);
+    w.perm = (int*)take((size_t)batch * n_pad * 4);
     w.removed = (u64*)take((size_t)batch * (n_pad / 64) * 8);
     w.count = (int*)take((size_t)batch * 4);
     // mask chunk: at most 16 MiB per image, whole 64-row tiles
@@ -1094,12 +1293,20 @@ int run_nms(const Workspace& w, const int* count, int batch, int n_pad, float io
             int* out_count, int max_keep, hipStream_t st) {
     const int words = n_pad / 64;
     pack_cols_kernel<<<dim3((n_pad + 255) / 256, batch), 256, 0, st>>>(w.sbox, count, n_pad, iou_thr, w.colpk, w.colk);
+    // rows grouped by size inside 1024-row blocks need chunks made of whole blocks
+    const bool windowed = n_pad % AREA_BLOCK == 0 && w.chunk_rows % AREA_BLOCK == 0;
+    if (windowed) area_order_kernel<<<dim3(n_pad / AREA_BLOCK, batch), 256, 0, st>>>(w.sbox, count, n_pad, w.perm);
     for (int r0 = 0; r0 < n_pad; r0 += w.chunk_rows) {
         const int r1 = r0 + w.chunk_rows < n_pad ? r0 + w.chunk_rows : n_pad;
         const int gx = (words + MASK_WAVES - 1) / MASK_WAVES, gy = (r1 - r0) / 64;
         dim3 grid(gx < 8 ? gx : 8, gy < 32 ? gy : 32, batch);
-        iou_mask_kernel<true><<<grid, 64 * MASK_WAVES, 0, st>>>(w.sbox, w.colpk, w.colk, count, w.removed, n_pad, r0,
-                                                                 r1, iou_thr, corner_rule, w.mask, w.mask_stride_img);
+        if (windowed)
+            iou_mask_win_kernel<<<grid, 64 * MASK_WAVES, 0, st>>>(w.sbox, w.perm, count, w.removed, n_pad,
+                                                                   r0, r1, iou_thr, corner_rule, w.mask,
+                                                                   w.mask_stride_img);
+        else
+            iou_mask_kernel<true><<<grid, 64 * MASK_WAVES, 0, st>>>(w.sbox, w.colpk, w.colk, count, w.removed, n_pad, r0,
+                                                                     r1, iou_thr, corner_rule, w.mask, w.mask_stride_img);
         nms_scan_kernel<<<batch, SCAN_THREADS, (size_t)words * 8, st>>>(w.mask, w.mask_stride_img, count, w.srow,
                                                                         w.removed, n_pad, r0, r1, out_idx, out_count,
                                                                         max_keep);
