@@ -518,7 +518,8 @@ pack_cols_kernel(const float4* __restrict__ sbox, const int* __restrict__ count,
     const float4 c = sbox[(size_t)b * n_pad + i];
     const BoxEx e = box_ex(c);
     colpk[(size_t)b * n_pad + i] = make_float4(c.x, c.y, e.x2, e.y2);
-    colk[(size_t)b * n_pad + i] = k_lo * e.area;
+    // an irregular box is marked by a NaN here (only ever read where the whole tile is regular, or as this mark)
+    colk[(size_t)b * n_pad + i] = e.special != 0.0f ? __builtin_nanf("") : k_lo * e.area;
 }
 
 // Grid: (GX, GY, image).  The number of candidates is only known on the device, so a fixed, small
@@ -701,6 +702,9 @@ iou_mask_kernel(const float4* __restrict__ sbox, const float4* __restrict__ colp
 // are skipped, the block's own 16 tiles are computed for all rows and masked per lane).
 //   inter <= ea: dx = fl(min(ax2, cx2) - max(ax, cx)) <= fl(ax2 - ax) = ew by monotone rounding, same for dy,
 //   and for dx, dy > 0 fl(dx * dy) <= fl(ew * eh); with dx <= 0 or dy <= 0 the product is <= 0.
+//   Likewise inter <= fl(min(ew_row, ew_col) * min(eh_row, eh_col)), which also separates shapes:
+//   a column is dropped when that bound, taken with the widest and the tallest row of the wave, stays
+//   below fl(min_row(k_lo * area_row) + k_lo * area_col) <= the pair's own threshold.
 // ------------------------------------------------------------------------------------------
 constexpr int AREA_BLOCK = 1024;
 
@@ -738,11 +742,11 @@ area_order_kernel(const float4* __restrict__ sbox, const int* __restrict__ count
 }
 
 __global__ void __launch_bounds__(64 * MASK_WAVES)
-iou_mask_win_kernel(const float4* __restrict__ sbox, const int* __restrict__ perm, const int* __restrict__ count, const u64* __restrict__ removed,
+iou_mask_win_kernel(const float4* __restrict__ sbox, const float4* __restrict__ colpk, const float* __restrict__ colk,
+                    const int* __restrict__ perm, const int* __restrict__ count, const u64* __restrict__ removed,
                     int n_pad, int row_begin, int row_end, float thr, int corner_rule, u64* __restrict__ mask,
                     size_t mask_stride_img) {
-    __shared__ float4 cols[MASK_WAVES][64];
-    __shared__ float4 colx[MASK_WAVES][64];
+    __shared__ float4 cols[MASK_WAVES][64];   // the tile's column boxes as they are (second look, exact arithmetic)
     // the surviving columns of the wave's tile, packed: (x, y, x2, y2), k_lo * area, original column
     __shared__ float4 pk_box[MASK_WAVES][72];
     __shared__ float pk_k[MASK_WAVES][72];
@@ -772,10 +776,14 @@ iou_mask_win_kernel(const float4* __restrict__ sbox, const int* __restrict__ per
         // the wave's window: smallest row threshold share, largest row "effective area"
         float wmin = live ? a_lo : __builtin_inff();
         float wmax = live ? (ae.x2 - a.x) * (ae.y2 - a.y) : -__builtin_inff();
+        float wmax_w = live ? ae.x2 - a.x : -__builtin_inff();     // widest and tallest row (rounded extents)
+        float wmax_h = live ? ae.y2 - a.y : -__builtin_inff();
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             wmin = fminf(wmin, __shfl_xor(wmin, o));
             wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+            wmax_w = fmaxf(wmax_w, __shfl_xor(wmax_w, o));
+            wmax_h = fmaxf(wmax_h, __shfl_xor(wmax_h, o));
         }
         for (int grp = tile0 / MASK_WAVES + blockIdx.x; grp < ngroups; grp += gridDim.x) {
             const int ct = __builtin_amdgcn_readfirstlane(grp * MASK_WAVES + wave);   // column tile (wave-uniform)
@@ -783,19 +791,24 @@ iou_mask_win_kernel(const float4* __restrict__ sbox, const int* __restrict__ per
             // every wave stages and reads only its own LDS slice: a wave-level barrier orders its accesses
             __builtin_amdgcn_wave_barrier();
             const bool cvalid = ct * 64 + lane < n;
-            const float4 c = cvalid ? boxes[ct * 64 + lane] : make_float4(0, 0, 0, 0);
-            const BoxEx e = box_ex(c);
-            cols[wave][lane] = c;
-            colx[wave][lane] = make_float4(e.x2, e.y2, k_lo * e.area, k_hi * e.area);
-            const u64 cspec = __ballot(e.special != 0.0f);
-            // columns some row of this wave could meet at the threshold (negated tests: NaN keeps the column)
-            const bool keep_col = cvalid && !((e.x2 - c.x) * (e.y2 - c.y) < wmin) && !(wmax < k_lo * e.area);
+            const size_t cidx = (size_t)b * n_pad + (size_t)ct * 64 + lane;
+            // the column's record from pack_cols_kernel: (x, y, x2, y2) and k_lo * area (NaN = irregular box)
+            const float4 cp = cvalid ? colpk[cidx] : make_float4(0, 0, 0, 0);
+            const float ck = cvalid ? colk[cidx] : __builtin_nanf("");
+            cols[wave][lane] = cvalid ? boxes[ct * 64 + lane] : make_float4(0, 0, 0, 0);
+            const u64 cspec = __ballot(ck != ck);
+            // columns some row of this wave could meet at the threshold (negated tests: NaN keeps the column);
+            // third test: inter <= min(ew_row, ew_col) * min(eh_row, eh_col), so boxes of similar area but
+            // different shape are dropped as well
+            const float cew = cp.z - cp.x, ceh = cp.w - cp.y;
+            const bool keep_col = cvalid && !(cew * ceh < wmin) && !(wmax < ck) &&
+                                  !(fminf(wmax_w, cew) * fminf(wmax_h, ceh) < wmin + ck);
             const u64 compat = __ballot(keep_col);
             const int ncompat = __popcll(compat);
             if (keep_col) {
                 const int pos = __popcll(compat & ((1ull << lane) - 1ull));
-                pk_box[wave][pos] = make_float4(c.x, c.y, e.x2, e.y2);
-                pk_k[wave][pos] = k_lo * e.area;
+                pk_box[wave][pos] = cp;
+                pk_k[wave][pos] = ck;
                 pk_j[wave][pos] = lane;
             }
             if (lane < 8) {   // a short last batch meets records that can never ask for the second look
@@ -831,7 +844,7 @@ iou_mask_win_kernel(const float4* __restrict__ sbox, const int* __restrict__ per
                             const int j = __builtin_amdgcn_readfirstlane(pk_j[wave][q0 + u]);
                             const float4 cc = cols[wave][j];
                             // need => product >= threshold > 0 => dy > 0 (dx > 0): the product is the intersection
-                            u64 sup = __ballot(inter[u] > a_hi + colx[wave][j].w) & need[u];
+                            u64 sup = __ballot(inter[u] > a_hi + k_hi * (cc.z * cc.w)) & need[u];
                             const u64 amb = need[u] & ~sup;                 // inside the guard band: exact arithmetic
                             if (amb) {
                                 const bool mine = (amb >> lane) & 1ull;
@@ -849,13 +862,14 @@ iou_mask_win_kernel(const float4* __restrict__ sbox, const int* __restrict__ per
 #pragma unroll 8
                         for (int jq = 31; jq >= 0; --jq) {      // descending: the shift-in below builds bit jq last-in-lowest
                             const int j = hh * 32 + jq;
+                            // a tile with an irregular box (or the last, partial one)
                             const float4 cc = cols[wave][j];
-                            const float4 ex = colx[wave][j];
+                            const BoxEx ce = box_ex(cc);
                             const float x1 = vmax(a.x, cc.x), y1 = vmax(a.y, cc.y);
-                            const float x2 = vmin(ae.x2, ex.x), y2 = vmin(ae.y2, ex.y);
+                            const float x2 = vmin(ae.x2, ce.x2), y2 = vmin(ae.y2, ce.y2);
                             const float inter = vmax(x2 - x1, 0.0f) * vmax(y2 - y1, 0.0f);
-                            const u64 keep_sure = __ballot(inter < a_lo + ex.z);
-                            u64 sup = __ballot(inter > a_hi + ex.w);
+                            const u64 keep_sure = __ballot(inter < a_lo + k_lo * ce.area);
+                            u64 sup = __ballot(inter > a_hi + k_hi * ce.area);
                             u64 amb = (~(keep_sure | sup) | row_special | (((cspec >> j) & 1ull) ? ~0ull : 0ull)) & live_mask;
                             if (amb) {
                                 const bool mine = (amb >> lane) & 1ull;
@@ -1301,7 +1315,7 @@ int run_nms(const Workspace& w, const int* count, int batch, int n_pad, float io
         const int gx = (words + MASK_WAVES - 1) / MASK_WAVES, gy = (r1 - r0) / 64;
         dim3 grid(gx < 8 ? gx : 8, gy < 32 ? gy : 32, batch);
         if (windowed)
-            iou_mask_win_kernel<<<grid, 64 * MASK_WAVES, 0, st>>>(w.sbox, w.perm, count, w.removed, n_pad,
+            iou_mask_win_kernel<<<grid, 64 * MASK_WAVES, 0, st>>>(w.sbox, w.colpk, w.colk, w.perm, count, w.removed, n_pad,
                                                                    r0, r1, iou_thr, corner_rule, w.mask,
                                                                    w.mask_stride_img);
         else
