@@ -83,6 +83,43 @@ def test_postprocess_matches_oracle_bit_exact(pp, n, ncls, dense, cthr, ithr):
         assert np.array_equal(res[b][0], rows)
 
 
+@pytest.mark.parametrize('ithr', [0.3, 0.5, 0.7])
+def test_nms_mixed_scales_and_irregular_boxes(pp, ithr):
+    """Boxes from 2 to 400 pixels (log-uniform, all shapes) in overlapping clusters, with zero, negative,
+    huge, infinite and NaN extents sprinkled in: the size windows of the mask kernel must drop only pairs
+    that cannot reach the threshold, and irregular boxes keep the reference arithmetic (a NaN IoU
+    suppresses, predict.py:90).  Kept indices against the restated loop, bit for bit."""
+    rng = np.random.default_rng(77)
+    n, ncls = 3500, 3
+    rows = np.zeros((2, n, 5 + ncls), np.float32)
+    for b in range(2):
+        centres = rng.uniform(40, 600, (60, 2))
+        c = centres[rng.integers(0, 60, n)] + rng.normal(0, 6, (n, 2))
+        wh = np.exp(rng.uniform(np.log(2.0), np.log(400.0), (n, 2)))
+        # families of near-identical boxes, so that suppression actually happens at every scale
+        fam = rng.integers(0, 400, n)
+        wh = wh[fam] * rng.uniform(0.9, 1.1, (n, 2))
+        c = c[fam] + rng.normal(0, 1.0, (n, 2)) * wh * 0.05
+        rows[b, :, 0:2] = c - wh / 2
+        rows[b, :, 2:4] = wh
+        rows[b, :, 4] = rng.uniform(0.05, 1, n)
+        rows[b, :, 5:] = rng.uniform(0.05, 1, (n, ncls))
+        bad = rng.choice(n, 40, replace=False)
+        rows[b, bad[0:8], 2] = 0.0
+        rows[b, bad[8:16], 3] = -5.0
+        rows[b, bad[16:22], 2:4] = 0.0
+        rows[b, bad[22:26], 2] = np.inf
+        rows[b, bad[26:30], 0] = np.nan
+        rows[b, bad[30:34], 2:4] = 1.0e20
+        rows[b, bad[34:40], 2:4] = 1.0e-25
+    with np.errstate(all='ignore'):
+        res = pp.nms_rows(torch.from_numpy(rows).cuda(), ithr).per_image()
+        for b in range(2):
+            want = opost.nms_indices(rows[b], ithr)
+            assert 200 < len(want) < n - 200
+            assert np.array_equal(res[b][1], want), f'image {b}'
+
+
 def test_postprocess_heads_equals_materialised(pp):
     size, ncls, batch = 160, 7, 4
     args = patterns.default_args(input_size=size, output_class=ncls)
