@@ -1313,7 +1313,11 @@ int run_nms(const Workspace& w, const int* count, int batch, int n_pad, float io
     for (int r0 = 0; r0 < n_pad; r0 += w.chunk_rows) {
         const int r1 = r0 + w.chunk_rows < n_pad ? r0 + w.chunk_rows : n_pad;
         const int gx = (words + MASK_WAVES - 1) / MASK_WAVES, gy = (r1 - r0) / 64;
-        dim3 grid(gx < 8 ? gx : 8, gy < 32 ? gy : 32, batch);
+        // the windowed kernel does its per-row-group set-up once per workgroup row: more rows, fewer column strides
+        // (about 256 workgroups per image either way)
+        const int ly = windowed ? 64 : 32;
+        const int lx = windowed ? (gy >= 64 ? 4 : 256 / gy) : 8;
+        dim3 grid(gx < lx ? gx : lx, gy < ly ? gy : ly, batch);
         if (windowed)
             iou_mask_win_kernel<<<grid, 64 * MASK_WAVES, 0, st>>>(w.sbox, w.colpk, w.colk, w.perm, count, w.removed, n_pad,
                                                                    r0, r1, iou_thr, corner_rule, w.mask,
