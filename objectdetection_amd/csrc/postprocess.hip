@@ -258,6 +258,14 @@ __device__ __forceinline__ u64 make_key(float score, int row) {
 }
 
 constexpr int FILTER_THREADS = 256;
+// The per-image candidate counters the filter kernel adds to sit in separate 128-byte lines: atomics
+// of different images then go to different L2 channels instead of queueing on one line.
+constexpr int COUNT_STRIDE = 32;
+
+__global__ void compact_counts_kernel(const int* __restrict__ padded, int batch, int n_pad, int* __restrict__ count) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) count[b] = padded[b * COUNT_STRIDE];
+}
 
 // Where the rows of a filter launch come from: up to three contiguous row ranges ("scales").
 // SRC 0/2 use one range (the (B,R,K) tensor), SRC 1 one range per raw head.
@@ -296,15 +304,31 @@ filter_kernel(FilterSrc fs, DecodeGeom g, int rows, int kdim, int rows_stage, fl
         const float* src = fs.base[s] + ((size_t)b * fs.rows_in[s] + lrow0) * kdim;
         const int total = nrow * kdim;
         const int nvec = (((uintptr_t)src & 15) == 0) ? total >> 2 : 0;
-        for (int v = threadIdx.x; v < nvec; v += FILTER_THREADS) {
-            const float4 t = ((const float4*)src)[v];
-            const int f = v << 2;
-            int r = f / kdim, k = f - r * kdim;
-            const float e[4] = {t.x, t.y, t.z, t.w};
+        // six loads per thread are issued before the first of them is used: one 16-byte load in flight per
+        // thread does not cover the latency of HBM
+        for (int v0 = threadIdx.x; v0 < nvec; v0 += 6 * FILTER_THREADS) {
+            float4 t[6];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                lds[r * ldk + k] = e[i];
-                if (++k == kdim) { k = 0; ++r; }
+            for (int q = 0; q < 6; ++q) {
+                const int v = v0 + q * FILTER_THREADS;
+                t[q] = v < nvec ? ((const float4*)src)[v] : make_float4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int v = v0 + q * FILTER_THREADS;
+                if (v >= nvec) break;
+                if (ldk == kdim) {   // odd row length: the LDS image is the memory image, one 16-byte store
+                    ((float4*)lds)[v] = t[q];
+                    continue;
+                }
+                const int f = v << 2;
+                int r = f / kdim, k = f - r * kdim;
+                const float e[4] = {t[q].x, t[q].y, t[q].z, t[q].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lds[r * ldk + k] = e[i];
+                    if (++k == kdim) { k = 0; ++r; }
+                }
             }
         }
         for (int f = (nvec << 2) + threadIdx.x; f < total; f += FILTER_THREADS) {
@@ -313,7 +337,11 @@ filter_kernel(FilterSrc fs, DecodeGeom g, int rows, int kdim, int rows_stage, fl
         }
     }
     __syncthreads();
-    for (int r = threadIdx.x; r < ((nrow + 63) & ~63); r += FILTER_THREADS) {
+    // One wave evaluates the (at most 64) staged rows.  Which one rotates with the workgroup index: the
+    // hardware places wave w of every workgroup on SIMD w % 4, a fixed choice would pile all the
+    // evaluation work of a CU onto one of its four SIMDs.
+    const int eval_wave = (blockIdx.x + blockIdx.y) & 3;
+    for (int r = (int)threadIdx.x - 64 * eval_wave; r >= 0 && r < ((nrow + 63) & ~63) && r < 64; r += FILTER_THREADS) {
         bool pass = false;
         u64 key = 0;
         if (r < nrow) {
@@ -355,7 +383,7 @@ filter_kernel(FilterSrc fs, DecodeGeom g, int rows, int kdim, int rows_stage, fl
         if (bal) {
             const int lane = threadIdx.x & 63;
             int base = 0;
-            if (lane == 0) base = atomicAdd(&count[b], __popcll(bal));
+            if (lane == 0) base = atomicAdd(&count[b * COUNT_STRIDE], __popcll(bal));
             base = __shfl(base, 0);
             const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
             if (pass && pos < n_pad) keys[(size_t)b * n_pad + pos] = key;
@@ -1259,6 +1287,7 @@ struct Workspace {
     u64* removed;
     u64* mask;
     int* count;
+    int* count_pad;  // the filter kernel's counters, one 128-byte line per image
     size_t mask_stride_img;  // words per image
     int chunk_rows;
     size_t total;
@@ -1279,6 +1308,7 @@ Workspace carve(char* base, int batch, int rows, int n_pad) {
     w.perm = (int*)take((size_t)batch * n_pad * 4);
     w.removed = (u64*)take((size_t)batch * (n_pad / 64) * 8);
     w.count = (int*)take((size_t)batch * 4);
+    w.count_pad = (int*)take((size_t)batch * COUNT_STRIDE * 4);
     // mask chunk: at most 16 MiB per image, whole 64-row tiles
     long long chunk = (16ll << 20) * 8 / n_pad;
     chunk = (chunk / 64) * 64;
@@ -1345,7 +1375,7 @@ int postprocess_impl(const float* pred, const DecodeGeom& g, int batch, int rows
     int rc;
     if ((rc = (int)hipMemsetAsync(w.keys, 0, (size_t)batch * n_pad * 8, st))) return rc;
     if ((rc = (int)hipMemsetAsync(w.removed, 0, (size_t)batch * (n_pad / 64) * 8, st))) return rc;
-    if ((rc = (int)hipMemsetAsync(w.count, 0, (size_t)batch * 4, st))) return rc;
+    if ((rc = (int)hipMemsetAsync(w.count_pad, 0, (size_t)batch * COUNT_STRIDE * 4, st))) return rc;
     if ((rc = (int)hipMemsetAsync(out_count, 0, (size_t)batch * 4, st))) return rc;
     // rows staged per workgroup: one wave's worth (about 22 KiB at 85 columns, so seven workgroups
     // per CU keep enough loads in flight), fewer when rows are very wide
@@ -1371,7 +1401,8 @@ int postprocess_impl(const float* pred, const DecodeGeom& g, int batch, int rows
     }
     dim3 fgrid(nstage, batch);
     filter_kernel<SRC><<<fgrid, FILTER_THREADS, (size_t)rows_stage * ldk * 4, st>>>(
-        fs, g, rows, kdim, rows_stage, conf_thr, w.rowbox, w.keys, n_pad, w.count);
+        fs, g, rows, kdim, rows_stage, conf_thr, w.rowbox, w.keys, n_pad, w.count_pad);
+    compact_counts_kernel<<<(batch + 255) / 256, 256, 0, st>>>(w.count_pad, batch, n_pad, w.count);
     if ((rc = sort_keys(w.keys, batch, n_pad, st))) return rc;
     gather_sorted_kernel<<<dim3((n_pad + 255) / 256, batch), 256, 0, st>>>(w.keys, w.rowbox, w.count, rows, n_pad,
                                                                            SRC >= 3, w.sbox, w.srow);
