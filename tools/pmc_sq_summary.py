@@ -20,7 +20,7 @@ def family(name):
     if m:
         _, ks, st, cg = (int(v) for v in m.groups())
         return 'conv%dx%d_s%d_%s' % (ks, ks, st, {1: 'c32', 2: 'c64', 4: 'c128'}[cg])
-    for key in ('conv_first2_kernel', 'conv_first_kernel', 'iou_mask_kernel', 'nms_scan_kernel', 'filter_kernel',
+    for key in ('conv_first2_kernel', 'conv_first_kernel', 'iou_mask_win_kernel', 'iou_mask_kernel', 'emit_heads_kernel', 'area_order_kernel', 'nms_scan_kernel', 'filter_kernel',
                 'emit_rows_kernel', 'bitonic_lds_kernel', 'bitonic_global_kernel', 'spp_pool3_kernel'):
         if key in name:
             return key
