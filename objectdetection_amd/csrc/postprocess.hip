@@ -1114,77 +1114,86 @@ emit_rows_kernel(const float* __restrict__ pred, DecodeGeom g, int rows, int kdi
 // values (anchor by comparisons, the cell split by a float reciprocal), the class columns are a plain
 // elementwise pass (one sigmoid per element, no divergence) and the 4 box columns of the wave's 4 rows
 // are handled together by 16 lanes.  Same arithmetic per element as decode_kernel + emit_rows_kernel<0>.
-struct EmitGeom { float inv_w[3]; };
+struct EmitGeom { float inv_w[3]; float inv_cls; };   // 1 / grid width per scale, 1 / (kdim - 4)
+
+constexpr int EMIT_HEADS_ROWS = 8;   // kept rows per wave and trip
 
 __global__ void __launch_bounds__(256)
 emit_heads_kernel(DecodeGeom g, EmitGeom eg, int kdim, const int* __restrict__ keep_idx, const int* __restrict__ keep_count,
                   int max_keep, const float* __restrict__ scale_xy, float* __restrict__ out) {
+    // per wave: the source pointer of its rows (lanes 0..7 work the row geometry out, one row each; doing
+    // it with wave-uniform scalar code costs ~100 scalar instructions per row and the CU has one scalar unit)
+    __shared__ const float* row_src[4][EMIT_HEADS_ROWS];
     const int b = blockIdx.y;
     const int nk = min(keep_count[b], max_keep);
     const float xs = scale_xy ? scale_xy[2 * b] : 1.0f;
     const float ys = scale_xy ? scale_xy[2 * b + 1] : 1.0f;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    for (int j0 = wave * EMIT_ROWS; j0 < nk; j0 += gridDim.x * 4 * EMIT_ROWS) {
-        const float* src[EMIT_ROWS];
-        float stride[EMIT_ROWS], aw[EMIT_ROWS], ah[EMIT_ROWS], fx[EMIT_ROWS], fy[EMIT_ROWS];
-#pragma unroll
-        for (int u = 0; u < EMIT_ROWS; ++u) {
-            const int j = min(j0 + u, nk - 1);   // the tail repeats the last row (loads only)
-            const int row = __builtin_amdgcn_readfirstlane(keep_idx[(size_t)b * max_keep + j]);
-            const int s = row >= g.rows_before[2] ? 2 : (row >= g.rows_before[1] ? 1 : 0);
-            const int lrow = row - g.rows_before[s];
-            const int hw = g.h[s] * g.w[s];
-            const int a = (lrow >= hw) + (lrow >= 2 * hw) + (lrow >= 3 * hw);
-            const int cell = lrow - a * hw;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wv;
+    const int ncls = kdim - 4;          // objectness + classes: the elementwise part of a row
+    for (int j0 = wave * EMIT_HEADS_ROWS; j0 < nk; j0 += gridDim.x * 4 * EMIT_HEADS_ROWS) {
+        // lanes 0..31: (row u = lane / 4, box column k = lane % 4); lanes 0..7 of them also publish the row pointer
+        const int u4 = (lane >> 2) & (EMIT_HEADS_ROWS - 1), kb = lane & 3;
+        const int ju = lane < EMIT_HEADS_ROWS ? lane : u4;
+        const int j = min(j0 + ju, nk - 1);     // the tail repeats the last row (loads only)
+        const int row = keep_idx[(size_t)b * max_keep + j];
+        const int s = row >= g.rows_before[2] ? 2 : (row >= g.rows_before[1] ? 1 : 0);
+        const int lrow = row - g.rows_before[s];
+        const int gw = s == 2 ? g.w[2] : (s == 1 ? g.w[1] : g.w[0]);
+        const int hw = (s == 2 ? g.h[2] : (s == 1 ? g.h[1] : g.h[0])) * gw;
+        const float* head = s == 2 ? g.head[2] : (s == 1 ? g.head[1] : g.head[0]);
+        const float* src = head + ((size_t)b * g.n_anchor * hw + lrow) * kdim;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < EMIT_HEADS_ROWS) row_src[wv][lane] = src;
+        __builtin_amdgcn_wave_barrier();
+        // ---- objectness and class columns of the 8 rows as one flat element list --------------------
+        const int total = EMIT_HEADS_ROWS * ncls;
+        for (int e0 = 0; e0 < total; e0 += 64) {
+            const int e = e0 + lane;
+            // floor(e / ncls): (e + 0.5) / ncls stays 0.5 / ncls away from an integer (e < 2^16, ncls < 2^12)
+            const int u = (int)(((float)e + 0.5f) * eg.inv_cls);
+            const int k = 4 + e - u * ncls;
+            if (e < total && j0 + u < nk) {
+                const float v = row_src[wv][u][k];
+                out[((size_t)b * max_keep + j0 + u) * kdim + k] = g.deploy ? sigmoid_f32(v) : v;
+            }
+        }
+        // ---- box columns: this lane's own row (lanes 8.. recomputed it for row lane / 4) ----------------
+        if (lane < 4 * EMIT_HEADS_ROWS) {
+            // geometry of row u4 (for lanes < 8 the values above belong to row `lane`, so redo them for u4)
+            const int j2 = min(j0 + u4, nk - 1);
+            const int row2 = keep_idx[(size_t)b * max_keep + j2];
+            const int s2 = row2 >= g.rows_before[2] ? 2 : (row2 >= g.rows_before[1] ? 1 : 0);
+            const int lrow2 = row2 - g.rows_before[s2];
+            const int gw2 = s2 == 2 ? g.w[2] : (s2 == 1 ? g.w[1] : g.w[0]);
+            const int hw2 = (s2 == 2 ? g.h[2] : (s2 == 1 ? g.h[1] : g.h[0])) * gw2;
+            const int a2 = (lrow2 >= hw2) + (lrow2 >= 2 * hw2) + (lrow2 >= 3 * hw2);
+            const int cell = lrow2 - a2 * hw2;
+            const float inv = s2 == 2 ? eg.inv_w[2] : (s2 == 1 ? eg.inv_w[1] : eg.inv_w[0]);
             // floor(cell / w): (cell + 0.5) / w stays 0.5 / w away from an integer, far more than the
             // rounding error of the float product for cell < 2^21 and w < 2^12
-            const int y = (int)(((float)cell + 0.5f) * eg.inv_w[s]);
-            const int x = cell - y * g.w[s];
-            src[u] = g.head[s] + ((size_t)b * g.n_anchor * hw + lrow) * kdim;
-            stride[u] = g.stride[s];
-            aw[u] = g.anchor[s][a][0];
-            ah[u] = g.anchor[s][a][1];
-            fx[u] = (float)x;
-            fy[u] = (float)y;
-        }
-        // class columns (and objectness): elementwise
-        for (int k0 = 0; k0 < kdim; k0 += 64) {
-            const int k = k0 + lane;
-            const bool live = k >= 4 && k < kdim;
-            float v[EMIT_ROWS];
+            const int y = (int)(((float)cell + 0.5f) * inv);
+            const int x = cell - y * gw2;
+            const float st = s2 == 2 ? g.stride[2] : (s2 == 1 ? g.stride[1] : g.stride[0]);
+            float an = 0.0f;
 #pragma unroll
-            for (int u = 0; u < EMIT_ROWS; ++u) v[u] = live ? src[u][k] : 0.0f;
+            for (int ss = 0; ss < 3; ++ss)
 #pragma unroll
-            for (int u = 0; u < EMIT_ROWS; ++u)
-                if (live && j0 + u < nk)
-                    out[((size_t)b * max_keep + j0 + u) * kdim + k] = g.deploy ? sigmoid_f32(v[u]) : v[u];
-        }
-        // box columns: lane l < 4 * EMIT_ROWS -> (row l / 4, column l % 4)
-        if (lane < 4 * EMIT_ROWS) {
-            const int u = lane >> 2, k = lane & 3;
-            const float* sp = src[0];
-            float st = stride[0], an = k == 2 ? aw[0] : ah[0], gc = k == 0 ? fx[0] : fy[0];
-#pragma unroll
-            for (int q = 1; q < EMIT_ROWS; ++q)
-                if (u == q) {
-                    sp = src[q];
-                    st = stride[q];
-                    an = k == 2 ? aw[q] : ah[q];
-                    gc = k == 0 ? fx[q] : fy[q];
-                }
-            const float t = sigmoid_f32(sp[k]);
+                for (int aa = 0; aa < 4; ++aa)
+                    if (ss == s2 && aa == a2) an = kb == 2 ? g.anchor[ss][aa][0] : g.anchor[ss][aa][1];
+            const float gc = kb == 0 ? (float)x : (float)y;
+            const float t = sigmoid_f32(row_src[wv][u4][kb]);
             // decode_value: (2t - 0.5 + cell) * stride for the centre, 4 t^2 * anchor for the extent
-            const float val = k < 2 ? (2.0f * t - 0.5f + gc) * st : (4.0f * (t * t)) * an;
+            const float val = kb < 2 ? (2.0f * t - 0.5f + gc) * st : (4.0f * (t * t)) * an;
             const float wh = __shfl_down(val, 2);      // the extent that belongs to this centre column
             float r;
-            if (k < 2) {   // x_min = cx - w/2 ; cx' = x_min + w/2 ; scaled.  Same roundings as the reference.
+            if (kb < 2) {   // x_min = cx - w/2 ; cx' = x_min + w/2 ; scaled.  Same roundings as the reference.
                 const float half = wh / 2.0f;
-                r = ((val - half) + half) * (k == 0 ? xs : ys);
+                r = ((val - half) + half) * (kb == 0 ? xs : ys);
             } else {
-                r = val * (k == 2 ? xs : ys);
+                r = val * (kb == 2 ? xs : ys);
             }
-            if (j0 + u < nk) out[((size_t)b * max_keep + j0 + u) * kdim + k] = r;
+            if (j0 + u4 < nk) out[((size_t)b * max_keep + j0 + u4) * kdim + kb] = r;
         }
     }
 }
@@ -1417,6 +1426,8 @@ int postprocess_impl(const float* pred, const DecodeGeom& g, int batch, int rows
             lean = g.w[s] < 4096 && (long long)g.h[s] * g.w[s] < (1 << 21);
             eg.inv_w[s] = 1.0f / (float)g.w[s];
         }
+        lean = lean && kdim - 4 < 4096;
+        eg.inv_cls = 1.0f / (float)(kdim - 4);
         if (lean)
             emit_heads_kernel<<<dim3(gx > 512 ? 512 : gx, batch), 256, 0, st>>>(g, eg, kdim, out_idx, out_count, max_keep,
                                                                                scale_xy, out_rows);
