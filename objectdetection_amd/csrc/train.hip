@@ -132,16 +132,34 @@ channel_reduce_kernel(const char* __restrict__ y, int y_ld, const char* __restri
 #pragma unroll
     for (int e = 0; e < N; ++e) { mine[e] = s0[e]; mine[N + e] = s1[e]; }
     __syncthreads();
-    if (r == 0) {
-#pragma unroll
-        for (int e = 0; e < N; ++e) {
-            double a0 = 0.0, a1 = 0.0;
-            for (int rr = 0; rr < rows; ++rr) {
-                const float* o = red + ((size_t)(rr * vecs + v) * 2) * N;
-                a0 += o[e]; a1 += o[N + e];
-            }
-            part[((size_t)blockIdx.x * 2 + 0) * C + v * N + e] = a0;
-            part[((size_t)blockIdx.x * 2 + 1) * C + v * N + e] = a1;
+    // Fold the rows in double precision with all threads: output o = (v, sum index, e) of the 2*C per
+    // workgroup is the column o of the [rows][2*C] float table; when 2*C < 256 the rows are cut into
+    // `slices` runs that are added in a fixed order afterwards (a few threads walking all rows alone
+    // took longer than streaming the activations for narrow layers).
+    const int nout = vecs * 2 * N;
+    double* dred = (double*)(red + (size_t)rows * nout);          // [slices][nout], behind the float table
+    const int nthr = blockDim.x;                                   // vecs * rows, at most 256
+    const int slices = nout >= nthr ? 1 : nthr / nout;
+    const int rows_per = (rows + slices - 1) / slices;
+    for (int t = threadIdx.x; t < nout * slices; t += nthr) {
+        const int o = t % nout, sl = t / nout;
+        double acc = 0.0;
+        const int r1 = min(rows, (sl + 1) * rows_per);
+        for (int rr = sl * rows_per; rr < r1; ++rr) acc += red[(size_t)rr * nout + o];
+        if (slices == 1) {
+            const int vv = o / (2 * N), which = (o / N) & 1, e = o % N;
+            part[((size_t)blockIdx.x * 2 + which) * C + vv * N + e] = acc;
+        } else {
+            dred[sl * nout + o] = acc;
+        }
+    }
+    if (slices > 1) {
+        __syncthreads();
+        for (int o = threadIdx.x; o < nout; o += nthr) {
+            double acc = 0.0;
+            for (int sl = 0; sl < slices; ++sl) acc += dred[sl * nout + o];
+            const int vv = o / (2 * N), which = (o / N) & 1, e = o % N;
+            part[((size_t)blockIdx.x * 2 + which) * C + vv * N + e] = acc;
         }
     }
 }
@@ -978,7 +996,8 @@ int red_geometry(int C, int dtype, int* vecs, int* rows) {
 }
 
 int red_blocks(size_t npix, int rows) {
-    size_t b = (npix + (size_t)rows * 16 - 1) / ((size_t)rows * 16);
+    // eight pixels per thread (two trips of four loads): short maps are bound by the chain of dependent trips
+    size_t b = (npix + (size_t)rows * 8 - 1) / ((size_t)rows * 8);
     if (b > RED_MAX_BLOCKS) b = RED_MAX_BLOCKS;
     if (b < 1) b = 1;
     return (int)b;
@@ -1097,7 +1116,7 @@ int odamd_bn_train_forward(const void* y, int y_ld, void* out, int out_ld, size_
     const int nblk = red_blocks(npix, rows);
     hipStream_t st = (hipStream_t)stream;
     const int per = dtype == ODAMD_DTYPE_F32 ? 4 : 8;
-    const size_t lds = (size_t)rows * vecs * 2 * per * sizeof(float);
+    const size_t lds = (size_t)rows * vecs * 2 * per * sizeof(float) + 256 * sizeof(double);
     double* part = (double*)workspace;
     if (dtype == ODAMD_DTYPE_F32)
         channel_reduce_kernel<ODAMD_DTYPE_F32, 0><<<nblk, vecs * rows, lds, st>>>((const char*)y, y_ld, nullptr, 0, npix, channels, vecs, rows, nullptr, nullptr, nullptr, nullptr, part);
@@ -1122,7 +1141,7 @@ int odamd_bn_silu_backward(void* y_dy, int y_ld, const void* dact, int dact_ld, 
     const int nblk = red_blocks(npix, rows);
     hipStream_t st = (hipStream_t)stream;
     const int per = dtype == ODAMD_DTYPE_F32 ? 4 : 8;
-    const size_t lds = (size_t)rows * vecs * 2 * per * sizeof(float);
+    const size_t lds = (size_t)rows * vecs * 2 * per * sizeof(float) + 256 * sizeof(double);
     double* part = (double*)workspace;
     float* mean_dz = (float*)((char*)workspace + odamd_bn_workspace_bytes(channels));
     float* mean_dzx = mean_dz + channels;
@@ -1147,7 +1166,7 @@ int odamd_bias_grad(const void* dy, int dy_ld, size_t npix, int channels, float*
     const int nblk = red_blocks(npix, rows);
     hipStream_t st = (hipStream_t)stream;
     const int per = dtype == ODAMD_DTYPE_F32 ? 4 : 8;
-    const size_t lds = (size_t)rows * vecs * 2 * per * sizeof(float);
+    const size_t lds = (size_t)rows * vecs * 2 * per * sizeof(float) + 256 * sizeof(double);
     double* part = (double*)workspace;
     if (dtype == ODAMD_DTYPE_F32)
         channel_reduce_kernel<ODAMD_DTYPE_F32, 2><<<nblk, vecs * rows, lds, st>>>((const char*)dy, dy_ld, nullptr, 0, npix, channels, vecs, rows, nullptr, nullptr, nullptr, nullptr, part);
