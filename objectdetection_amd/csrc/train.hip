@@ -996,8 +996,7 @@ int red_geometry(int C, int dtype, int* vecs, int* rows) {
 }
 
 int red_blocks(size_t npix, int rows) {
-    // eight pixels per thread (two trips of four loads): short maps are bound by the chain of dependent trips
-    size_t b = (npix + (size_t)rows * 8 - 1) / ((size_t)rows * 8);
+    size_t b = (npix + (size_t)rows * 16 - 1) / ((size_t)rows * 16);
     if (b > RED_MAX_BLOCKS) b = RED_MAX_BLOCKS;
     if (b < 1) b = 1;
     return (int)b;
