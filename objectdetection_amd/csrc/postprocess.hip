@@ -457,6 +457,9 @@ gather_sorted_kernel(const u64* __restrict__ keys, const float4* __restrict__ ro
 // predict.py:35-41 for boxes (x_min, y_min, w, h); returns true when the candidate is
 // suppressed, i.e. NOT (iou < thr).  NaN (0/0 for two empty boxes) suppresses, as in numpy.
 __device__ __forceinline__ bool suppresses(const float4 a, const float4 c, float thr) {
+    // np.maximum / np.minimum hand a NaN operand on (fmaxf / fminf drop it): a NaN corner makes the
+    // intersection and with it the IoU NaN, which suppresses.  NaN extents reach the IoU through the areas.
+    if (a.x != a.x || a.y != a.y || c.x != c.x || c.y != c.y) return true;
     const float x1 = fmaxf(a.x, c.x);
     const float y1 = fmaxf(a.y, c.y);
     const float x2 = fminf(a.x + a.z, c.x + c.z);
@@ -521,7 +524,9 @@ __global__ void __launch_bounds__(256) iou_pairs_kernel(const float4* __restrict
     const float x1 = fmaxf(p.x, c.x), y1 = fmaxf(p.y, c.y);
     const float x2 = fminf(p.x + p.z, c.x + c.z), y2 = fminf(p.y + p.w, c.y + c.w);
     const float inter = fmaxf(x2 - x1, 0.0f) * fmaxf(y2 - y1, 0.0f);
-    out[i] = inter / (p.z * p.w + c.z * c.w - inter);
+    // np.maximum / np.minimum hand a NaN corner on where fmaxf / fminf drop it
+    const bool nan_corner = p.x != p.x || p.y != p.y || c.x != c.x || c.y != c.y;
+    out[i] = nan_corner ? __builtin_nanf("") : inter / (p.z * p.w + c.z * c.w - inter);
 }
 
 // Column operands of the mask kernel's common path per sorted box: (x, y, x2, y2) in `colpk` and

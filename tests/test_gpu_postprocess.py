@@ -83,7 +83,7 @@ def test_postprocess_matches_oracle_bit_exact(pp, n, ncls, dense, cthr, ithr):
         assert np.array_equal(res[b][0], rows)
 
 
-@pytest.mark.parametrize('ithr', [0.3, 0.5, 0.7])
+@pytest.mark.parametrize('ithr', [0.3, 0.5, 0.7, 0.02, 0.98, 0.0, 1.0, 1.5])
 def test_nms_mixed_scales_and_irregular_boxes(pp, ithr):
     """Boxes from 2 to 400 pixels (log-uniform, all shapes) in overlapping clusters, with zero, negative,
     huge, infinite and NaN extents sprinkled in: the size windows of the mask kernel must drop only pairs
@@ -116,7 +116,8 @@ def test_nms_mixed_scales_and_irregular_boxes(pp, ithr):
         res = pp.nms_rows(torch.from_numpy(rows).cuda(), ithr).per_image()
         for b in range(2):
             want = opost.nms_indices(rows[b], ithr)
-            assert 200 < len(want) < n - 200
+            if 0.1 < ithr < 0.9:
+                assert 200 < len(want) < n - 200
             assert np.array_equal(res[b][1], want), f'image {b}'
 
 
