@@ -37,6 +37,13 @@ def test_decode_nms_iou_api_match_reference_fixtures(golden):
     pc = _pc(640, 0.5, 0.5, model=_model(64, 1))
     a = g['iou.a']
     assert np.array_equal(pc.iou(a[0:1], a), g['iou.val'], equal_nan=True)
+    # NaN corners: np.maximum / np.minimum of predict.py:35-38 hand the NaN on to the IoU
+    bad = a.copy()
+    bad[1, 0] = np.nan
+    bad[2, 1] = np.nan
+    with np.errstate(all='ignore'):
+        assert np.array_equal(pc.iou(bad[0:1], bad), opost.iou_xywh(bad[0], bad), equal_nan=True)
+        assert np.array_equal(pc.iou(bad[1:2], bad), opost.iou_xywh(bad[1], bad), equal_nan=True)
     # stand-alone _nms on pre-filtered rows
     cand, idx = opost.filter_indices(g['spread.pred'], 0.5)
     keep = opost.nms_indices(cand, 0.5)
