@@ -254,6 +254,9 @@ __device__ __forceinline__ u64 make_key(float score, int row) {
     if (score == 0.0f) score = 0.0f;  // -0 -> +0, numpy orders them as equal
     uint32_t u = __float_as_uint(score);
     u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+    // np.argsort puts every NaN (either sign, any payload) behind all numbers, so the reversed order
+    // (predict.py:84) starts with them: one key above +inf for all of them
+    if (score != score) u = 0xFFFFFFFFu;
     return ((u64)u << 32) | (uint32_t)row;
 }
 
@@ -367,7 +370,12 @@ filter_kernel(FilterSrc fs, DecodeGeom g, int rows, int kdim, int rows_stage, fl
                     // the sigmoid is monotone, so the largest class probability is the sigmoid of the
                     // largest class logit: one exp per surviving row instead of one per class
                     float m = p[5];
-                    for (int k = 6; k < kdim; ++k) m = fmaxf(m, p[k]);
+                    bool cls_nan = m != m;      // np.max (predict.py:83) hands a NaN on, fmaxf drops it
+                    for (int k = 6; k < kdim; ++k) {
+                        m = fmaxf(m, p[k]);
+                        cls_nan = cls_nan || p[k] != p[k];
+                    }
+                    if (cls_nan) m = __builtin_nanf("");
                     if (SRC == 1) m = sigmoid_f32(m);
                     key = make_key(conf * m, SRC >= 3 ? ~(row0 + r) : row0 + r);
                     if (SRC >= 3) {   // extents as the corner form x_max - x_min carries them (train_class.py:79)

@@ -112,6 +112,12 @@ def test_nms_mixed_scales_and_irregular_boxes(pp, ithr):
         rows[b, bad[26:30], 0] = np.nan
         rows[b, bad[30:34], 2:4] = 1.0e20
         rows[b, bad[34:40], 2:4] = 1.0e-25
+        # NaN scores of either sign (np.argsort puts all of them last, so the reversed order starts with them)
+        nan_neg = np.array([0xFFC00000], np.uint32).view(np.float32)[0]
+        odd = rng.choice(n, 6, replace=False)
+        rows[b, odd[0:2], 4] = np.nan
+        rows[b, odd[2:4], 4] = nan_neg
+        rows[b, odd[4:6], 6] = np.nan
     with np.errstate(all='ignore'):
         res = pp.nms_rows(torch.from_numpy(rows).cuda(), ithr).per_image()
         for b in range(2):
