@@ -119,7 +119,26 @@ def train_leg(a, dev, rank, world, dist, steps, warmup, amp=False):
     last = l.tolist()
     if not all(v == v and abs(v) < 1e30 for v in last):
         raise RuntimeError(f'training leg diverged (amp={amp}): losses {last}')
+    # convolution work of a step: forward + data gradient + weight gradient = 3 x the forward count of the
+    # plan (2 FLOP per multiply-add; the first layer has no data gradient, which this overstates by < 1 %)
+    from objectdetection_amd import engine as _engine
+    pb = _engine.PlanBuilder(1, _engine.F32, dev)      # lowering only: no buffers are allocated
+    tc.model._emit(pb, (a.size, a.size))
+    fwd_flops = 0.0                                     # per image
+    for op in pb.ops:
+        if op['kind'] == 'first':
+            fwd_flops += 2.0 * op['y'].h * op['y'].w * op['mod'].conv.out_channels * 27
+        elif op['kind'] == 'conv':
+            cv = op['mod'].conv
+            fwd_flops += 2.0 * op['y'].h * op['y'].w * cv.out_channels * op['k'] ** 2 * cv.in_channels
+        elif op['kind'] == 'head':
+            cv = op['mod'].output
+            fwd_flops += 2.0 * op['x'].h * op['x'].w * cv.out_channels * cv.in_channels
+    ips = world * a.train_batch * steps / dt
+    tflops = 3.0 * fwd_flops * ips / 1e12
+    peak = MFMA_PEAK_TFLOPS['bf16' if amp else 'f32']
     return {'images_per_sec': world * a.train_batch * steps / dt, 'ms_per_step': dt / steps * 1e3,
+            'conv_tflops': tflops, 'mfma_peak_tflops': peak * world, 'frac_of_mfma_peak': tflops / (peak * world),
             'global_batch': world * a.train_batch, 'dtype': 'bf16 (f32 accumulate / statistics / master weights)' if amp else 'f32',
             'classes': a.train_classes, 'steps': steps,
             'parallelism': f'dp{world}' + (' (RCCL all-reduce, 3 buckets behind backward)' if world > 1 else ''),
