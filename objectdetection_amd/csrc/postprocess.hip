@@ -1355,14 +1355,16 @@ int sort_keys(u64* keys, int batch, int n_pad, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-int run_nms(const Workspace& w, const int* count, int batch, int n_pad, float iou_thr, int corner_rule, int* out_idx,
+int run_nms(const Workspace& w, const int* count, int batch, int rows, int n_pad, float iou_thr, int corner_rule, int* out_idx,
             int* out_count, int max_keep, hipStream_t st) {
     const int words = n_pad / 64;
     pack_cols_kernel<<<dim3((n_pad + 255) / 256, batch), 256, 0, st>>>(w.sbox, count, n_pad, iou_thr, w.colpk, w.colk);
     // rows grouped by size inside 1024-row blocks need chunks made of whole blocks
     const bool windowed = n_pad % AREA_BLOCK == 0 && w.chunk_rows % AREA_BLOCK == 0;
     if (windowed) area_order_kernel<<<dim3(n_pad / AREA_BLOCK, batch), 256, 0, st>>>(w.sbox, count, n_pad, w.perm);
-    for (int r0 = 0; r0 < n_pad; r0 += w.chunk_rows) {
+    // an image has at most `rows` candidates: chunks beyond them would be empty launches
+    const int r_end = rows < n_pad ? rows : n_pad;
+    for (int r0 = 0; r0 < r_end; r0 += w.chunk_rows) {
         const int r1 = r0 + w.chunk_rows < n_pad ? r0 + w.chunk_rows : n_pad;
         const int gx = (words + MASK_WAVES - 1) / MASK_WAVES, gy = (r1 - r0) / 64;
         // the windowed kernel does its per-row-group set-up once per workgroup row: more rows, fewer column strides
@@ -1428,7 +1430,7 @@ int postprocess_impl(const float* pred, const DecodeGeom& g, int batch, int rows
     if ((rc = sort_keys(w.keys, batch, n_pad, st))) return rc;
     gather_sorted_kernel<<<dim3((n_pad + 255) / 256, batch), 256, 0, st>>>(w.keys, w.rowbox, w.count, rows, n_pad,
                                                                            SRC >= 3, w.sbox, w.srow);
-    if ((rc = run_nms(w, w.count, batch, n_pad, iou_thr, SRC >= 3, out_idx, out_count, max_keep, st))) return rc;
+    if ((rc = run_nms(w, w.count, batch, rows, n_pad, iou_thr, SRC >= 3, out_idx, out_count, max_keep, st))) return rc;
     if (cand_count)
         if ((rc = (int)hipMemcpyAsync(cand_count, w.count, (size_t)batch * 4, hipMemcpyDeviceToDevice, st))) return rc;
     if (out_rows) {
