@@ -124,9 +124,14 @@ class GradReducer:
         if self.world > 1:
             a, b = self.bounds[i]
             if self.host_staged:
-                # gloo stages CUDA tensors through the host and was seen to stall when the stream still
-                # has work queued behind the bucket; RCCL (the production backend) is stream ordered
+                # gloo (rehearsals on one GPU only) stages CUDA tensors through the host itself and was seen to
+                # stall now and then with several asynchronous buckets in flight: do the staging here and
+                # reduce host tensors synchronously.  RCCL (the production backend) is stream ordered.
                 torch.cuda.current_stream().synchronize()
+                host = self.flat[a:b].cpu()
+                self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
+                self.flat[a:b].copy_(host)
+                return
             self.handles.append(self.dist.all_reduce(self.flat[a:b], op=self.dist.ReduceOp.SUM, group=self.group,
                                                      async_op=True))
 
