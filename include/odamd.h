@@ -27,6 +27,7 @@ extern "C" {
 #define ODAMD_E_ALIGN (-2)     /* pointer or channel count violates the stated alignment */
 #define ODAMD_E_WORKSPACE (-3) /* workspace too small */
 #define ODAMD_E_SHAPE (-4)     /* shapes inconsistent with each other */
+#define ODAMD_E_LIMIT (-5)     /* size beyond the fixed capacity of an allocation-free entry point */
 
 #define ODAMD_DTYPE_F32 0
 #define ODAMD_DTYPE_BF16 1
@@ -105,6 +106,20 @@ int odamd_postprocess_heads(const odamd_decode_desc* d, float conf_thr, float io
  * of them are candidates; kept rows are returned unchanged, in keep order. */
 int odamd_nms_rows(const float* rows_xywh, int batch, int rows, int kdim, float iou_thr, int n_pad, float* out_rows,
                    int* out_idx, int* out_count, int max_keep, void* workspace, size_t workspace_bytes, void* stream);
+
+/* odamd_nms_rows without a workspace argument and without any allocation.  It has no counterpart in
+ * the reference: it exists for callers that cannot allocate device memory around the call (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  The workspace is a static
+ * device array of ODAMD_STATIC_SCRATCH_MIB MiB that every GPU the library runs on holds until the
+ * process ends; n_pad is the power of two >= rows (at least 64).  Sizes whose workspace
+ * (odamd_postprocess_workspace_bytes(batch, rows, kdim, 0)) exceeds the array are rejected with
+ * ODAMD_E_LIMIT -- e.g. 1 image of 8192 rows, 6 of 4096, 24 of 2048 fit.  Results equal odamd_nms_rows
+ * bit for bit.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU
+ * (different streams or threads) race; serialise them.  The first call on a device looks the array's
+ * address up (hipGetSymbolAddress); make that call outside stream capture. */
+#define ODAMD_STATIC_SCRATCH_MIB 16
+int odamd_nms_rows_static(const float* rows_xywh, int batch, int rows, int kdim, float iou_thr, float* out_rows,
+                          int* out_idx, int* out_count, int max_keep, void* stream);
 
 /* Candidate selection + NMS of the validation metric (train_class.py:340-346 with :76-83): pred is
  * the NON-deployed (B,R,K) tensor (cx,cy,w,h,raw conf,raw cls..).  Rows with conf > conf_thr become

@@ -60,6 +60,8 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'odamd_nms_rows': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                c_void_p, c_size_t, c_void_p]),
+    'odamd_nms_rows_static': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int,
+                                      c_void_p]),
     'odamd_metric_nms': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'odamd_metric_nms_rows': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int,

@@ -13,6 +13,7 @@ const char* odamd_error_string(int code) {
         case ODAMD_E_ALIGN: return "pointer or channel count violates the required alignment";
         case ODAMD_E_WORKSPACE: return "workspace too small";
         case ODAMD_E_SHAPE: return "inconsistent shapes";
+        case ODAMD_E_LIMIT: return "size exceeds the fixed capacity of this allocation-free entry point";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown odamd error";
     }
 }

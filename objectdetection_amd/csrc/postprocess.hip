@@ -20,9 +20,39 @@
 #include <stdlib.h>
 #include "odamd.h"
 
+#include <mutex>
+
+// Scratch of odamd_nms_rows_static, the entry point that allocates nothing.  Every GPU the library
+// runs on holds its own copy of this array, at its own address, until the process ends.  In host
+// code the name `scratch` is only a handle for hipGetSymbolAddress: the device address it returns
+// (kept per device in static_scratch()) is what kernels, memsets and copies are given.
+constexpr size_t STATIC_SCRATCH_BYTES = (size_t)ODAMD_STATIC_SCRATCH_MIB << 20;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
 namespace {
 
 typedef unsigned long long u64;
+
+// Device address of `scratch` on the current device (looked up once per device).
+int static_scratch(void** out) {
+    constexpr int MAX_DEVICES = 64;
+    static std::mutex mu;
+    static void* ptr[MAX_DEVICES] = {};
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= MAX_DEVICES) return ODAMD_E_ARG;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        if (!p) return ODAMD_E_ARG;
+        ptr[dev] = p;
+    }
+    *out = ptr[dev];
+    return ODAMD_OK;
+}
 
 // 1 / (1 + e^-x): the library exponential and the hardware reciprocal (1 ulp; the IEEE division
 // sequence is ten more vector instructions per value and these kernels are issue-bound without it).
@@ -1550,6 +1580,23 @@ int odamd_nms_rows(const float* rows_xywh, int batch, int rows, int kdim, float 
     DecodeGeom g = {};
     return postprocess_impl<2>(rows_xywh, g, batch, rows, kdim, 0.0f, iou_thr, nullptr, n_pad, out_rows, out_idx,
                                out_count, nullptr, max_keep, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int odamd_nms_rows_static(const float* rows_xywh, int batch, int rows, int kdim, float iou_thr, float* out_rows,
+                          int* out_idx, int* out_count, int max_keep, void* stream) {
+    if (!rows_xywh || batch < 1 || rows < 1) return ODAMD_E_ARG;
+    int n_pad = next_pow2(rows);
+    if (n_pad < 64) n_pad = 64;
+    if (n_pad > (1 << 18)) return ODAMD_E_LIMIT;
+    // the same workspace layout as odamd_nms_rows, carved out of this GPU's static array
+    const size_t need = carve(nullptr, batch, rows, n_pad).total;
+    if (need > STATIC_SCRATCH_BYTES) return ODAMD_E_LIMIT;
+    void* ws = nullptr;
+    const int rc = static_scratch(&ws);
+    if (rc) return rc;
+    DecodeGeom g = {};
+    return postprocess_impl<2>(rows_xywh, g, batch, rows, kdim, 0.0f, iou_thr, nullptr, n_pad, out_rows, out_idx,
+                               out_count, nullptr, max_keep, ws, STATIC_SCRATCH_BYTES, (hipStream_t)stream);
 }
 
 int odamd_metric_nms(const float* pred, int batch, int rows, int kdim, float conf_thr, float nms_thr, int n_pad,
