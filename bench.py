@@ -45,6 +45,7 @@ def parse():
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                    help='process-group backend (gloo + --share-gpu rehearses the multi-rank path on a one-GPU box)')
     p.add_argument('--share-gpu', action='store_true', help='every rank uses cuda:0 (rehearsal only)')
+    p.add_argument('--splits', type=int, default=1, help='concurrent sub-batches of a step (independent images on separate streams)')
     return p.parse_args()
 
 
@@ -190,7 +191,7 @@ def main():
     # two HIP streams: the network of step i+1 overlaps the decode/NMS of step i; every step's
     # network AND post-processing complete inside the timed region (the closing fence waits for both)
     from objectdetection_amd.predict import detect_pipeline
-    pipe = detect_pipeline(model, a.conf, a.iou, anchor=margs.anchor, input_size=a.size)
+    pipe = detect_pipeline(model, a.conf, a.iou, anchor=margs.anchor, input_size=a.size, splits=a.splits)
 
     def step():
         return pipe.submit(x)

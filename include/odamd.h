@@ -183,9 +183,22 @@ typedef struct {
     int in_upzero2;    /* 1: input is zero-upsampled x2 on the fly (value at even (y,x), zero elsewhere): with
                           flipped, transposed weights this is the data gradient of a stride-2 3x3 convolution */
     int accumulate;    /* 1: NHWC output is added to the destination (gradient accumulation) */
+    int w_packed;      /* 1: w is in the fragment-ordered layout of odamd_conv_weight_layout (only where that
+                          function returns 1 for this descriptor) */
 } odamd_conv_desc;
 
 int odamd_conv_forward(const odamd_conv_desc* d, void* stream);
+
+/* Deep stride-1 bf16 layers on small maps are served by a kernel that moves its operands global -> LDS
+ * without registers and wants the weights in the order its matrix fragments are read.  Returns 1 and sets
+ * (cout_groups G, chunk_bytes CB) when such a form exists for the layer `d` describes (pointers in `d` are
+ * ignored), else 0.  Packed layout, T = ksize^2 taps, cout padded with zero rows to a multiple of 32*G,
+ * cin*2 a multiple of CB:
+ *   [cout / (32 G)][cin * 2 / CB][G][T][CB / 32][2][32][8] bf16,
+ *   element (cb, chunk, g, tap, s, hh, r, e) = w[cb*32*G + g*32 + r][tap][chunk*CB/2 + s*16 + hh*8 + e]
+ * with w the plain [cout][ky][kx][cin] array.  Same arithmetic as the plain form (cbs.forward,
+ * model/layer.py:12-16). */
+int odamd_conv_weight_layout(const odamd_conv_desc* d, int* cout_groups, int* chunk_bytes);
 
 /* First layer: float32 NCHW image (B,3,H,W) -> NHWC activations; replaces cbs0 of
  * yolov7.forward (model/yolov7.py:114).  w: [cout][ky][kx][3] float32; scale/shift may both be

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libodamd.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(f'{LIB_PATH} not found: build it with `make -C objectdetection_amd/csrc` '
@@ -36,7 +36,7 @@ class ConvDesc(C.Structure):
                 ('batch', c_int), ('h', c_int), ('w_in', c_int), ('cin', c_int), ('cout', c_int),
                 ('x_ld', c_int), ('y_ld', c_int), ('ksize', c_int), ('stride', c_int), ('act', c_int),
                 ('dtype', c_int), ('in_pool2', c_int), ('out_nchw_f32', c_int), ('in_upzero2', c_int),
-                ('accumulate', c_int)]
+                ('accumulate', c_int), ('w_packed', c_int)]
 
 
 class PackDesc(C.Structure):
@@ -71,6 +71,7 @@ SIGNATURES = {
     'odamd_iou_pairs': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     'odamd_iou_mask': (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p]),
     'odamd_conv_forward': (c_int, [C.POINTER(ConvDesc), c_void_p]),
+    'odamd_conv_weight_layout': (c_int, [C.POINTER(ConvDesc), C.POINTER(c_int), C.POINTER(c_int)]),
     'odamd_conv_first_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                          c_int, c_int, c_int, c_int, c_void_p]),
     'odamd_conv_first2_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define ODAMD_ABI_VERSION 1
+#define ODAMD_ABI_VERSION 2
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = one 16-byte MFMA fragment
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;

@@ -71,11 +71,31 @@ __device__ __forceinline__ float silu(float v) {
 // NHWC epilogue shared by the convolution kernels.  `acc[i][j]`: the wave's results for pixel
 // group i (32 pixels, lane r = pixel) and channel group j; `opix[i]`: output pixel index of (group i,
 // lane r) relative to `ybase`, -1 when outside; `stage`: wave-private LDS slice of 32 * (CGW*128 + 16) bytes.
+// Per-lane affine constants of the NHWC epilogue: lane `lane` of a wave that holds channels [cw0, cw0 + 32*CGW)
+// owns CPL = 16 / element-size consecutive channels in the read-back.  Loaded unconditionally from clamped
+// (always valid) addresses so that all loads are in flight together; callers issue this before their main
+// loop, which hides the latency completely (conditional loads serialise into one memory round trip each).
+template <int DT, int CGW>
+struct Affine {
+    static constexpr int CPL = 16 / Elem<DT>::SIZE;
+    float scl[CPL], shf[CPL];
+    __device__ __forceinline__ void load(const float* __restrict__ scale, const float* __restrict__ shift, int lane, int cw0,
+                                         int Cout) {
+        constexpr int LPR = CGW * 32 / CPL;
+        const int c_lane = cw0 + (lane % LPR) * CPL;
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) {
+            const int c = min(c_lane + e, Cout - 1);
+            scl[e] = scale ? scale[c] : 1.0f;
+            shf[e] = shift ? shift[c] : 0.0f;
+        }
+    }
+};
+
 template <int DT, int PGW, int CGW>
 __device__ __forceinline__ void nhwc_epilogue(const f32x16_t (&acc)[PGW][CGW], const int (&opix)[PGW], char* stage, int lane,
-                                              int cw0, size_t ybase, const float* __restrict__ scale,
-                                              const float* __restrict__ shift, int Cout, char* __restrict__ y, int y_ld,
-                                              int act, int accum) {
+                                              int cw0, size_t ybase, const Affine<DT, CGW>& aff, int Cout,
+                                              char* __restrict__ y, int y_ld, int act, int accum) {
     constexpr int ES = Elem<DT>::SIZE;
     const int r = lane & 31, h = lane >> 5;
     // NHWC: the wave parks its raw f32 accumulators in a private LDS slice [32 pixels][32*CGW
@@ -87,15 +107,11 @@ __device__ __forceinline__ void nhwc_epilogue(const f32x16_t (&acc)[PGW][CGW], c
     constexpr int RS = NCH * 4 + 16;         // padded LDS row (f32)
     constexpr int LPR = NCH / CPL;           // lanes per pixel row
     constexpr int RPP = 64 / LPR;            // pixel rows per pass
-        const int part = lane % LPR;
+    const int part = lane % LPR;
     const int c_lane = cw0 + part * CPL;
-    float scl[CPL], shf[CPL];
+    const float (&scl)[CPL] = aff.scl;
+    const float (&shf)[CPL] = aff.shf;
 #pragma unroll
-    for (int e = 0; e < CPL; ++e) {
-        scl[e] = (scale && c_lane + e < Cout) ? scale[c_lane + e] : 1.0f;
-        shf[e] = (shift && c_lane + e < Cout) ? shift[c_lane + e] : 0.0f;
-    }
-    #pragma unroll
     for (int i = 0; i < PGW; ++i) {
 #pragma unroll
         for (int j = 0; j < CGW; ++j)
@@ -154,6 +170,72 @@ __device__ __forceinline__ void nhwc_epilogue(const f32x16_t (&acc)[PGW][CGW], c
     }
 }
 
+// Branch-free form of nhwc_epilogue for the common case (channel block entirely inside Cout, overwrite, output
+// tensor below 2 GiB): the per-pass loop has no control flow, so the LDS reads, the SiLU chain and the stores
+// of consecutive passes overlap (with branches every pass is its own serial LDS -> VALU -> store round trip).
+// Stores go through a buffer resource: lanes whose pixel lies outside the image get offset 0xFFFFFFFF,
+// which the range check of the resource drops, so no lane mask is needed.
+// `ytensor`: the address the pixel indices in `opix` (+ ybase) are relative to; `ybytes`: bytes addressable from it.
+template <int DT, int PGW, int CGW, bool ACT>
+__device__ __forceinline__ void nhwc_epilogue_fast(const f32x16_t (&acc)[PGW][CGW], const int (&opix)[PGW], char* stage, int lane,
+                                                   int cw0, int ybase, const Affine<DT, CGW>& aff, char* ytensor,
+                                                   unsigned ybytes, int y_ld) {
+    constexpr int ES = Elem<DT>::SIZE;
+    const int r = lane & 31, h = lane >> 5;
+    constexpr int CPL = 16 / ES;
+    constexpr int NCH = CGW * 32;
+    constexpr int RS = NCH * 4 + 16;
+    constexpr int LPR = NCH / CPL;
+    constexpr int RPP = 64 / LPR;
+    const int part = lane % LPR;
+    const int c_lane = cw0 + part * CPL;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ytensor, 0, ybytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PGW; ++i) {
+#pragma unroll
+        for (int j = 0; j < CGW; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(stage + r * RS + (j * 32 + 8 * g + 4 * h) * 4) =
+                    make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int row = ps * RPP + lane / LPR;
+            const int op = __shfl(opix[i], row);
+            float v[CPL];
+#pragma unroll
+            for (int e = 0; e < CPL; e += 4) {
+                const float4 t = *(const float4*)(stage + row * RS + (part * CPL + e) * 4);
+                v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+            }
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) v[e] = v[e] * aff.scl[e] + aff.shf[e];
+            if (ACT) {
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) v[e] = silu<DT>(v[e]);
+            }
+            u32x4 pk;
+            if constexpr (DT == ODAMD_DTYPE_F32) {
+                pk = u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+            } else {
+                pk.x = f32x2_to_bf16x2(v[0], v[1]);
+                pk.y = f32x2_to_bf16x2(v[2], v[3]);
+                pk.z = f32x2_to_bf16x2(v[4 % CPL], v[5 % CPL]);
+                pk.w = f32x2_to_bf16x2(v[6 % CPL], v[7 % CPL]);
+            }
+            const int voff = op >= 0 ? ((ybase + op) * y_ld + c_lane) * ES : -1;
+            __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, voff, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Host side: may the branch-free epilogue serve this output?  (whole channel blocks, 32-bit byte offsets)
+static inline bool fast_epilogue_ok(size_t npix, int y_ld, int es, int Cout, int block_channels, int accum) {
+    return !accum && Cout % block_channels == 0 && npix * (size_t)y_ld * es < ((size_t)1 << 31);
+}
+
 struct ConvP {
     const char* x; const char* w; const float* scale; const float* shift; char* y;
     int B, H, W, Ho, Wo, Cin, Cout, x_ld, y_ld;
@@ -165,6 +247,8 @@ struct ConvP {
     int upskip; // upz with even tiles: pixel groups are parity classes and skip the taps that only meet zeros
     int nblocks;
     float inv_tw, inv_iw;  // 1 / TW, 1 / IW for the index splits below
+    int fast_epi;          // the branch-free epilogue applies (fast_epilogue_ok)
+    unsigned ybytes;       // bytes addressable from y (for the buffer resource of the fast epilogue)
 };
 
 // floor(v / d) for 0 <= v < 2^21 given inv = 1.0f / d (d < 2^12): (v + 0.5) * inv stays at least 0.5 / d
@@ -314,6 +398,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
     }
 
     const int cbytes = p.Cin * ES;
+    Affine<DT, CGW> aff;
+    if (!p.nchw) aff.load(p.scale, p.shift, lane, co0 + wc * CGW * 32, p.Cout);
     ODAMD_FETCH(0)
     for (int c0 = 0; c0 < cbytes; c0 += CKB) {
         ODAMD_COMMIT()
@@ -390,8 +476,14 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
         return;
     }
     // NHWC: transposed through a wave-private LDS slice (see nhwc_epilogue)
-    nhwc_epilogue<DT, PGW, CGW>(acc, opix, lds + wave * (32 * (CGW * 128 + 16)), lane, cw0, (size_t)b * p.Ho * p.Wo, p.scale,
-                                p.shift, p.Cout, p.y, p.y_ld, p.act, p.accum);
+    char* stage = lds + wave * (32 * (CGW * 128 + 16));
+    if (p.fast_epi) {
+        if (cw0 >= p.Cout) return;
+        if (p.act) nhwc_epilogue_fast<DT, PGW, CGW, true>(acc, opix, stage, lane, cw0, b * p.Ho * p.Wo, aff, p.y, p.ybytes, p.y_ld);
+        else nhwc_epilogue_fast<DT, PGW, CGW, false>(acc, opix, stage, lane, cw0, b * p.Ho * p.Wo, aff, p.y, p.ybytes, p.y_ld);
+        return;
+    }
+    nhwc_epilogue<DT, PGW, CGW>(acc, opix, stage, lane, cw0, (size_t)b * p.Ho * p.Wo, aff, p.Cout, p.y, p.y_ld, p.act, p.accum);
 }
 #undef ODAMD_FETCH
 #undef ODAMD_COMMIT
@@ -408,6 +500,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
 struct StreamP {
     const char* x; const char* w; const float* scale; const float* shift; char* y;
     int npix, Cin, Cout, x_ld, y_ld, ntiles, act, accum, w_off;
+    int fast_epi; unsigned ybytes;
 };
 
 template <int DT, int CG, int WP, int WC, int NPF>
@@ -453,6 +546,8 @@ __global__ void __launch_bounds__(256) conv1x1_stream_kernel(StreamP p) {
     const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
     u32x4 v_in[NPF];
     const size_t tile_bytes = (size_t)128 * p.x_ld * ES;
+    Affine<DT, CGW> aff;
+    aff.load(p.scale, p.shift, lane, co0 + wc * CGW * 32, p.Cout);
 #define ODAMD_SFETCH(T)                                                                          \
     {                                                                                            \
         const char* xb_ = p.x + (size_t)(T) * tile_bytes;                                        \
@@ -520,11 +615,24 @@ __global__ void __launch_bounds__(256) conv1x1_stream_kernel(StreamP p) {
             const int q = t * 128 + (wp * PGW + i) * 32 + r;
             opix[i] = q < p.npix ? q : -1;
         }
-        nhwc_epilogue<DT, PGW, CGW>(acc, opix, lds + wave * (32 * (CGW * 128 + 16)), lane, co0 + wc * CGW * 32, 0, p.scale,
-                                    p.shift, p.Cout, p.y, p.y_ld, p.act, p.accum);
+        char* stage = lds + wave * (32 * (CGW * 128 + 16));
+        const int cw0 = co0 + wc * CGW * 32;
+        if (p.fast_epi) {
+            if (cw0 < p.Cout) {
+                if (p.act) nhwc_epilogue_fast<DT, PGW, CGW, true>(acc, opix, stage, lane, cw0, 0, aff, p.y, p.ybytes, p.y_ld);
+                else nhwc_epilogue_fast<DT, PGW, CGW, false>(acc, opix, stage, lane, cw0, 0, aff, p.y, p.ybytes, p.y_ld);
+            }
+        } else {
+            nhwc_epilogue<DT, PGW, CGW>(acc, opix, stage, lane, cw0, 0, aff, p.Cout, p.y, p.y_ld, p.act, p.accum);
+        }
     }
 #undef ODAMD_SFETCH
 }
+
+// 64 bytes of zeros: the source line of LDS-DMA pieces that lie outside the image (zero padding)
+__device__ __attribute__((aligned(64))) const unsigned char g_zero_line[64] = {};
+
+#include "conv_dma.h"
 
 // ------------------------------------------------------------------------------------------
 // first layer, float32 compute: float32 NCHW image, 3 input channels, 3x3 stride 1 -> NHWC
@@ -749,7 +857,8 @@ __device__ __forceinline__ void first_weights_frag(const float* __restrict__ w0,
 __global__ void __launch_bounds__(64 * first2::TH)
 conv_first2_kernel(const float* __restrict__ img, const float* __restrict__ w0, const float* __restrict__ scale0,
                    const float* __restrict__ shift0, const char* __restrict__ w1, const float* __restrict__ scale1,
-                   const float* __restrict__ shift1, char* __restrict__ y, int H, int W, int Ho, int Wo, int y_ld) {
+                   const float* __restrict__ shift1, char* __restrict__ y, int H, int W, int Ho, int Wo, int y_ld,
+                   unsigned ybytes) {
     using namespace first2;
     constexpr int DT = ODAMD_DTYPE_BF16;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -765,6 +874,8 @@ conv_first2_kernel(const float* __restrict__ img, const float* __restrict__ w0, 
     for (int tap = 0; tap < 9; ++tap) a[tap] = *(const u32x4*)(w1 + ((r * 9 + tap) * 16 + 8 * h) * 2);
     u32x4 wa[3];
     first_weights_frag(w0, r, h, wa);
+    Affine<DT, 1> aff1;
+    aff1.load(scale1, shift1, lane, 0, 32);
     float sc[8], sh[8];   // channels 4h+e (e < 4) and 8+4h+(e-4)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -849,8 +960,10 @@ conv_first2_kernel(const float* __restrict__ img, const float* __restrict__ w0, 
     __syncthreads();   // every wave is done reading the patch: its memory becomes the epilogue slices
     const int oy = oy0 + ty, ox = ox0 + r;
     int opix[1] = {(oy < Ho && ox < Wo) ? oy * Wo + ox : -1};
-    nhwc_epilogue<DT, 1, 1>(acc, opix, lds + wave * (32 * (128 + 16)), lane, 0, (size_t)b * Ho * Wo, scale1, shift1, 32, y,
-                            y_ld, 1, 0);
+    if (ybytes)
+        nhwc_epilogue_fast<DT, 1, 1, true>(acc, opix, lds + wave * (32 * (128 + 16)), lane, 0, b * Ho * Wo, aff1, y, ybytes, y_ld);
+    else
+        nhwc_epilogue<DT, 1, 1>(acc, opix, lds + wave * (32 * (128 + 16)), lane, 0, (size_t)b * Ho * Wo, aff1, 32, y, y_ld, 1, 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1013,7 +1126,8 @@ struct TileChoice { int th, tw, ih, iw; bool ok; };
 
 // Pick the output patch (TH x TW <= npix pixels) that stages the fewest input pixels overall
 // and whose halo patch + weight slab fit in LDS.
-TileChoice choose_tile(int Ho, int Wo, int npix, int ks, int st, int ps, size_t w_bytes, int max_pix, bool even = false) {
+TileChoice choose_tile(int Ho, int Wo, int npix, int ks, int st, int ps, size_t w_bytes, int max_pix, bool even = false,
+                       size_t lds_limit = LDS_LIMIT) {
     const int cand[] = {Wo, 64, 40, 32, 20, 16, 8};
     TileChoice best = {0, 0, 0, 0, false};
     double best_cost = 1e30;
@@ -1026,7 +1140,7 @@ TileChoice choose_tile(int Ho, int Wo, int npix, int ks, int st, int ps, size_t 
         for (; th >= (even ? 2 : 1); th -= (even ? 2 : 1)) {
             const int ih = (th - 1) * st + ks, iw = (tw - 1) * st + ks;
             if (ih * iw > max_pix) continue;
-            if ((((size_t)ih * iw * ps + 255) & ~(size_t)255) + w_bytes > (size_t)LDS_LIMIT) continue;
+            if ((((size_t)ih * iw * ps + 255) & ~(size_t)255) + w_bytes > lds_limit) continue;
             const double tiles = (double)((Wo + tw - 1) / tw) * ((Ho + th - 1) / th);
             const double cost = tiles * (ih * iw + 0.25 * npix);  // staged pixels + a share for idle lanes
             if (cost < best_cost) { best_cost = cost; best = {th, tw, ih, iw, true}; }
@@ -1055,6 +1169,11 @@ int launch_conv(ConvP p, hipStream_t st) {
     p.tiles_y = (p.Ho + t.th - 1) / t.th;
     p.ncb = (p.Cout + 32 * CG - 1) / (32 * CG);
     p.nblocks = p.B * p.tiles_x * p.tiles_y * p.ncb;
+    {
+        const size_t npix = (size_t)p.B * p.Ho * p.Wo;
+        p.fast_epi = !p.nchw && fast_epilogue_ok(npix, p.y_ld, ES, p.Cout, 32 * (CG / WC), p.accum);
+        p.ybytes = p.fast_epi ? (unsigned)((npix - 1) * p.y_ld * ES + (size_t)p.Cout * ES) : 0u;
+    }
     size_t lds = (((size_t)t.ih * t.iw * PS + 255) & ~(size_t)255) + w_bytes;
     const size_t epi = (size_t)4 * 32 * ((CG / WC) * 32 * 4 + 16);    // the waves' f32 transpose slices
     if (lds < epi) lds = epi;
@@ -1082,6 +1201,8 @@ int launch_stream(const ConvP& c, hipStream_t st) {
     p.x = c.x; p.w = c.w; p.scale = c.scale; p.shift = c.shift; p.y = c.y;
     p.npix = c.B * c.H * c.W; p.Cin = c.Cin; p.Cout = c.Cout; p.x_ld = c.x_ld; p.y_ld = c.y_ld;
     p.ntiles = (p.npix + 127) / 128; p.act = c.act; p.accum = c.accum;
+    p.fast_epi = fast_epilogue_ok((size_t)p.npix, p.y_ld, ES, p.Cout, 32 * (CG / WC), p.accum);
+    p.ybytes = p.fast_epi ? (unsigned)(((size_t)p.npix - 1) * p.y_ld * ES + (size_t)p.Cout * ES) : 0u;
     const int cbytes = c.Cin * ES, rsb = cbytes + 16;
     const size_t epi = (size_t)4 * 32 * ((CG / WC) * 128 + 16);
     size_t in_bytes = (size_t)128 * rsb;
@@ -1105,6 +1226,91 @@ int launch_stream(const ConvP& c, hipStream_t st) {
     else return ODAMD_E_SHAPE;
 #undef ODAMD_STREAM
     return (int)hipGetLastError();
+}
+
+// ---- LDS-DMA kernel: configuration, launch -------------------------------------------------------
+struct DmaConfig { int ks, pg, cg, wp, wc, ckb, nbuf; };
+#ifdef ODAMD_LAB
+DmaConfig g_lab_force = {};      // tools/micro/conv_lab.hip tries instantiations through this
+#endif
+
+// Which conv_dma_kernel instantiation serves a layer (bf16, stride 1, plain NHWC in / out), or pg == 0.
+DmaConfig dma_config(const ConvP& p, int ks, int stride, int dtype) {
+    DmaConfig none = {};
+    if (dtype != ODAMD_DTYPE_BF16 || stride != 1 || p.pool || p.upz || p.nchw || p.accum) return none;
+    const long long npix = (long long)p.B * p.H * p.W;
+#ifdef ODAMD_LAB
+    if (g_lab_force.pg) return g_lab_force.ks == ks ? g_lab_force : none;
+#endif
+    // measured against conv_igemm_kernel / conv1x1_stream_kernel at batch 64 (tools/micro/conv_lab.hip): the DMA
+    // kernel wins where K = taps * cin is deep and the map is small (weights dominate the staged bytes)
+    if (ks == 3) {
+        if (p.Cin < 64 || p.Cout < 64 || p.H * p.W > 80 * 80) return none;
+        return {3, 8, 2, 4, 1, 32, 2};
+    }
+    if (ks == 1) {
+        if (p.Cin % 32 || p.Cin < 256 || p.Cout < 128 || npix > 64ll * 40 * 40) return none;
+        return {1, 4, 4, 2, 2, 64, 3};
+    }
+    return none;
+}
+
+template <int KS, int PG, int CG, int WP, int WC, int CKB, int NBUF>
+int launch_dma(const ConvP& c, hipStream_t st) {
+    constexpr int PARTS = CKB / 16, KSTEPS = CKB / 32, TAPS = KS * KS, NW = WP * WC;
+    constexpr size_t W_BYTES = (size_t)CG * TAPS * KSTEPS * 1024;
+    constexpr size_t LDS_MAX = 160 * 1024;
+    DmaP p = {};
+    p.x = c.x; p.w = c.w; p.scale = c.scale; p.shift = c.shift; p.y = c.y;
+    p.Cin = c.Cin; p.Cout = c.Cout; p.x_ld = c.x_ld; p.y_ld = c.y_ld; p.act = c.act;
+    if (KS == 1) {            // no spatial structure: the batch is one row of pixels
+        p.B = 1; p.H = 1; p.W = c.B * c.H * c.W;
+        p.TH = 1; p.TW = 32 * PG; p.IH = 1; p.IW = p.TW;
+    } else {
+        p.B = c.B; p.H = c.H; p.W = c.W;
+        // per buffer: PARTS * npad * 16 + W_BYTES; the chooser sees bytes per staged pixel and the rest
+        const size_t per_buf_limit = LDS_MAX / NBUF;
+        TileChoice t = choose_tile(c.H, c.W, 32 * PG, KS, 1, PARTS * 16, W_BYTES + PARTS * 16 * 64, dma_max_in_pix(KS, PG), false,
+                                   per_buf_limit);
+        if (!t.ok) return ODAMD_E_SHAPE;
+        p.TH = t.th; p.TW = t.tw; p.IH = t.ih; p.IW = t.iw;
+    }
+    p.npad = (p.IH * p.IW + 63) & ~63;
+    p.inv_tw = 1.0f / (float)p.TW; p.inv_iw = 1.0f / (float)p.IW;
+    p.tiles_x = (p.W + p.TW - 1) / p.TW;
+    p.tiles_y = (p.H + p.TH - 1) / p.TH;
+    p.ncb = (p.Cout + 32 * CG - 1) / (32 * CG);
+    p.nchunk = p.Cin * 2 / CKB;
+    p.nblocks = p.B * p.tiles_x * p.tiles_y * p.ncb;
+    {
+        const size_t npix = (size_t)p.B * p.H * p.W;
+        p.fast_epi = fast_epilogue_ok(npix, p.y_ld, 2, p.Cout, 32 * (CG / WC), 0);
+        p.ybytes = p.fast_epi ? (unsigned)((npix - 1) * p.y_ld * 2 + (size_t)p.Cout * 2) : 0u;
+    }
+    p.inv_ncb = 1.0f / (float)p.ncb; p.inv_tiles = 1.0f / (float)(p.tiles_x * p.tiles_y); p.inv_tiles_x = 1.0f / (float)p.tiles_x;
+    // div_small is exact for dividends below 2^21 and divisors below 2^12
+    if (p.nblocks >= (1 << 21) || p.tiles_x * p.tiles_y >= 4096 || p.ncb >= 4096) return ODAMD_E_SHAPE;
+    size_t lds = (size_t)NBUF * ((size_t)PARTS * p.npad * 16 + W_BYTES);
+    const size_t epi = (size_t)NW * 32 * ((CG / WC) * 128 + 16);
+    if (lds < epi) lds = epi;
+    if (lds > LDS_MAX) return ODAMD_E_SHAPE;
+    auto k = conv_dma_kernel<KS, PG, CG, WP, WC, CKB, NBUF>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k<<<p.nblocks, 64 * NW, lds, st>>>(p);
+    return (int)hipGetLastError();
+}
+
+int dispatch_dma(const ConvP& p, const DmaConfig& g, hipStream_t st) {
+#define ODAMD_DMA_CASE(KS, PG, CG, WP, WC, CKB, NBUF)                                                          \
+    if (g.ks == KS && g.pg == PG && g.cg == CG && g.wp == WP && g.wc == WC && g.ckb == CKB && g.nbuf == NBUF)  \
+        return launch_dma<KS, PG, CG, WP, WC, CKB, NBUF>(p, st);
+    ODAMD_DMA_CASE(3, 8, 2, 4, 1, 32, 2)
+    ODAMD_DMA_CASE(1, 4, 4, 2, 2, 64, 3)
+#ifdef LAB_DMA_VARIANTS
+    LAB_DMA_VARIANTS
+#endif
+#undef ODAMD_DMA_CASE
+    return ODAMD_E_ARG;
 }
 
 template <int DT>
@@ -1156,8 +1362,10 @@ int check_vec(const void* x, const void* y, int c, int x_ld, int y_ld, int dtype
 
 extern "C" {
 
-int odamd_conv_forward(const odamd_conv_desc* d, void* stream) {
-    if (!d || !d->x || !d->w || !d->y) return ODAMD_E_ARG;
+// Validates a descriptor and turns it into kernel parameters.
+static int fill_conv_params(const odamd_conv_desc* d, ConvP* out, bool need_pointers) {
+    if (!d) return ODAMD_E_ARG;
+    if (need_pointers && (!d->x || !d->w || !d->y)) return ODAMD_E_ARG;
     if (d->batch < 1 || d->h < 1 || d->w_in < 1 || d->cin < 1 || d->cout < 1) return ODAMD_E_ARG;
     if (d->dtype != ODAMD_DTYPE_F32 && d->dtype != ODAMD_DTYPE_BF16) return ODAMD_E_ARG;
     if (!((d->ksize == 1 && d->stride == 1) || (d->ksize == 3 && (d->stride == 1 || d->stride == 2)))) return ODAMD_E_ARG;
@@ -1183,7 +1391,30 @@ int odamd_conv_forward(const odamd_conv_desc* d, void* stream) {
         if (d->y_ld < d->cout) return ODAMD_E_SHAPE;
         if (((uintptr_t)d->y & (4 * es - 1)) || (d->y_ld * es) % (4 * es)) return ODAMD_E_ALIGN;
     }
+    *out = p;
+    return ODAMD_OK;
+}
+
+int odamd_conv_weight_layout(const odamd_conv_desc* d, int* cout_groups, int* chunk_bytes) {
+    ConvP p;
+    if (!cout_groups || !chunk_bytes || fill_conv_params(d, &p, false) != ODAMD_OK) return 0;
+    const DmaConfig g = dma_config(p, d->ksize, d->stride, d->dtype);
+    if (!g.pg) return 0;
+    *cout_groups = g.cg;
+    *chunk_bytes = g.ckb;
+    return 1;
+}
+
+int odamd_conv_forward(const odamd_conv_desc* d, void* stream) {
+    ConvP p;
+    const int rc = fill_conv_params(d, &p, true);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (d->w_packed) {
+        const DmaConfig g = dma_config(p, d->ksize, d->stride, d->dtype);
+        if (!g.pg) return ODAMD_E_ARG;        // this layer has no packed-weight form (odamd_conv_weight_layout returned 0)
+        return dispatch_dma(p, g, st);
+    }
     return d->dtype == ODAMD_DTYPE_F32 ? dispatch_conv<ODAMD_DTYPE_F32>(p, d->ksize, d->stride, st)
                                        : dispatch_conv<ODAMD_DTYPE_BF16>(p, d->ksize, d->stride, st);
 }
@@ -1216,8 +1447,10 @@ int odamd_conv_first2_forward(const float* image, const float* w0, const float* 
     const int ho = (h - 1) / 2 + 1, wo = (w_in - 1) / 2 + 1;
     dim3 grid((wo + first2::TW - 1) / first2::TW, (ho + first2::TH - 1) / first2::TH, batch);
     static_assert(first2::LDS_BYTES <= 64 * 1024, "fits the default LDS limit of a workgroup");
+    const size_t npix = (size_t)batch * ho * wo;
+    const unsigned ybytes = fast_epilogue_ok(npix, y_ld, 2, 32, 32, 0) ? (unsigned)((npix - 1) * y_ld * 2 + 64) : 0u;
     conv_first2_kernel<<<grid, 64 * first2::TH, first2::LDS_BYTES, (hipStream_t)stream>>>(
-        image, w0, scale0, shift0, (const char*)w1, scale1, shift1, (char*)y, h, w_in, ho, wo, y_ld);
+        image, w0, scale0, shift0, (const char*)w1, scale1, shift1, (char*)y, h, w_in, ho, wo, y_ld, ybytes);
     return (int)hipGetLastError();
 }
 

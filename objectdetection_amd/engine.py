@@ -29,6 +29,17 @@ CH_ALIGN = 16            # channel granule of buffer slices in bf16 plans (f32 p
 
 _compute_dtype = None    # None: follow the parameters' dtype
 
+# Kernels write parameters and BatchNorm running buffers through raw pointers (the optimizer step, the
+# train-mode forward), which torch's per-tensor `_version` counters do not see.  Every such write bumps
+# this generation; cached inference plans compare it (together with the `_version`s) before they run and
+# re-fold their weights when it moved.
+_weights_generation = [0]
+
+
+def touch_weights():
+    """Tell cached inference plans that parameters or BN buffers were modified behind torch's back."""
+    _weights_generation[0] += 1
+
 
 def set_compute_dtype(name):
     """Force the arithmetic type of all plans: 'bf16', 'f32' or None (follow parameter dtype:
@@ -169,6 +180,20 @@ def _pack_weight(w, x_act, dtype):
     return packed.to(_TORCH_DT[dtype]).contiguous()
 
 
+def _pack_fragments(w, groups, chunk_bytes):
+    """Plain packed weights (cout, k, k, cin_phys) bf16 -> the fragment-ordered layout of
+    odamd_conv_weight_layout: [cout / 32G][chunk][G][tap][k-step][2][32][8], zero rows up to a multiple
+    of 32 * G output channels."""
+    cout, k, _, cin = w.shape
+    taps, per = k * k, 32 * groups
+    ncb = (cout + per - 1) // per
+    nch, ksn = cin * 2 // chunk_bytes, chunk_bytes // 32
+    if ncb * per != cout:
+        w = torch.cat([w, torch.zeros((ncb * per - cout, k, k, cin), dtype=w.dtype, device=w.device)])
+    v = w.reshape(ncb, groups, 32, taps, nch, ksn, 2, 8)          # (cb, g, r, tap, chunk, s, half, e)
+    return v.permute(0, 4, 1, 3, 5, 6, 2, 7).contiguous().view(-1)
+
+
 class Plan:
     """Lowered module: buffers allocated, descriptors built, ready to run."""
 
@@ -243,7 +268,7 @@ class Plan:
 
     # ---- weights ---------------------------------------------------------------------------
     def _versions(self):
-        v = 0
+        v = _weights_generation[0] << 32
         for op in self.b.convs:
             for m in op.get('mods', [op['mod']]) + ([op['mod0']] if 'mod0' in op else []):
                 if op['kind'] == 'head':
@@ -282,7 +307,8 @@ class Plan:
                     op['shift'].copy_(sh)
                 else:
                     mods = op.get('mods', [m])
-                    op['w'].copy_(torch.cat([_pack_weight(q.conv.weight, op['x'], self.b.dtype).view(-1) for q in mods]))
+                    plain = torch.cat([_pack_weight(q.conv.weight, op['x'], self.b.dtype) for q in mods])
+                    op['w'].copy_(_pack_fragments(plain, *op['frag']) if op.get('frag') else plain.view(-1))
                     folded = [_fold_bn(q.bn) for q in mods]
                     op['scale'].copy_(torch.cat([f[0] for f in folded]))
                     op['shift'].copy_(torch.cat([f[1] for f in folded]))
@@ -314,6 +340,13 @@ class Plan:
                     d.y, d.y_ld, d.out_nchw_f32 = out.data_ptr(), 0, 1
                 else:
                     d.y, d.y_ld, d.out_nchw_f32 = self._ptr(op['y']), self._ld(op['y']), 0
+                    # deep small-map layers: the library wants the weights in fragment order
+                    g, cb = C.c_int(0), C.c_int(0)
+                    if lib.odamd_conv_weight_layout(C.byref(d), C.byref(g), C.byref(cb)):
+                        op['frag'] = (g.value, cb.value)
+                        per = 32 * g.value
+                        op['w'] = torch.empty((cout + per - 1) // per * per * k * k * x.cphys, dtype=dt, device=dev)
+                        d.w, d.w_packed = op['w'].data_ptr(), 1
                 self.keep.append(d)
                 self.launches.append((lib.odamd_conv_forward, [C.byref(d)], 'conv', None))
                 ho = (d.h // (2 if op['pool'] else 1) + 2 * ((k - 1) // 2) - k) // op['s'] + 1
@@ -442,7 +475,7 @@ def run_module(module, x, emit=None):
     if not x.is_cuda:
         raise RuntimeError('objectdetection_amd blocks run on the GPU only (no CPU fallback)')
     if module.training:
-        raise RuntimeError('stand-alone blocks run in eval mode; training goes through yolov7.forward')
+        return _run_module_train(module, x, emit)
     dtype = compute_dtype_for(module)
     key = (id(module), tuple(x.shape), dtype, x.device.index)
     plan = _plans.get(key)
@@ -456,3 +489,48 @@ def run_module(module, x, emit=None):
         _plans[key] = plan
     y = plan.run(x.detach().float().contiguous())
     return y.clone() if x.dtype == torch.float32 else y.to(x.dtype)
+
+
+class _BlockTrain(torch.autograd.Function):
+    """Autograd node of one stand-alone block in train mode (batch-statistics BatchNorm): backward
+    replays the block's reverse launch list, ADDS the parameter gradients to `param.grad` and returns
+    the input gradient."""
+
+    @staticmethod
+    def forward(ctx, x, hook, plan):
+        ctx.plan, ctx.x = plan, x
+        return plan.forward(x).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        plan = ctx.plan
+        plan.gout_nchw.copy_(grad_out)
+        plan.backward(ctx.x)
+        return plan.dx_nchw.clone(), None, None
+
+
+def _run_module_train(module, x, emit=None):
+    """Train-mode forward of a stand-alone block (model/layer.py:12-16: every block of the reference is an
+    ordinary autograd module).  The block's parameters move into flat storage on first use (or stay in
+    the flat storage of the network they already belong to); `param.grad` accumulates like torch's."""
+    from . import train_engine
+    if emit is not None:
+        raise RuntimeError('train mode is not available for this module')
+    state = None
+    for p in module.parameters():
+        state = getattr(p, '_odamd_flat', None)
+        break
+    if state is None:
+        state = train_engine.FlatState(module)
+    dtype = BF16 if getattr(module, 'train_dtype', 'f32') == 'bf16' else F32
+    plans = module.__dict__.setdefault('_odamd_train_plans', {})
+    key = (tuple(x.shape), dtype, x.device.index)
+    plan = plans.get(key)
+    if plan is None:
+        b, c, h, w = x.shape
+        plan = plans[key] = train_engine.TrainPlan(module, state, b, h, dtype, block_input=(c, h, w))
+    hook = module.__dict__.get('_odamd_hook')
+    if hook is None:
+        hook = module.__dict__['_odamd_hook'] = torch.zeros(1, device=x.device, requires_grad=True)
+    y = _BlockTrain.apply(x.detach().float().contiguous() if not x.requires_grad else x.float().contiguous(), hook, plan)
+    return y if x.dtype == torch.float32 else y.to(x.dtype)

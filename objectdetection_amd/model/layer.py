@@ -15,10 +15,19 @@ from .. import postprocess as _post
 
 
 def _w(module):
-    """Output channels of a block."""
+    """Output channels of a block (derived from its convolutions, so that modules restored from a
+    reference-format pickle, which carry only the reference's attributes, work as well)."""
     if isinstance(module, cbs):
         return module.conv.out_channels
-    return module.out_channels
+    if isinstance(module, elan):
+        return module.cbs5.conv.out_channels
+    if isinstance(module, elan_h):
+        return module.cbs7.conv.out_channels
+    if isinstance(module, mp):
+        return module.cbs1.conv.out_channels + module.cbs3.conv.out_channels
+    if isinstance(module, sppcspc):
+        return module.cbs11.conv.out_channels
+    raise TypeError(type(module))
 
 
 class _Block(torch.nn.Module):
@@ -81,7 +90,6 @@ class elan(_Block):  # in_ -> out_, same spatial size
         self.sequential3 = torch.nn.Sequential(*(cbs(width[1 + n + i], width[2 + n + i], 3, 1) for i in range(n)))
         self.concat4 = concat()
         self.cbs5 = cbs(width[0] + width[1] + width[1 + n] + width[1 + 2 * n], width[2 + 2 * n], 1, 1)
-        self.out_channels = width[2 + 2 * n]
 
     def _emit(self, pb, x, out=None):
         n = len(self.sequential2)
@@ -111,7 +119,6 @@ class elan_h(_Block):  # in_ -> out_, same spatial size
         self.cbs5 = cbs(width[4], width[5], 3, 1)
         self.concat6 = concat()
         self.cbs7 = cbs(sum(width[:6]), width[6], 1, 1)
-        self.out_channels = width[6]
 
     def _emit(self, pb, x, out=None):
         stages = [self.cbs0, self.cbs1, self.cbs2, self.cbs3, self.cbs4, self.cbs5]
@@ -137,7 +144,6 @@ class mp(_Block):  # in_ -> out_, half spatial size
         self.cbs2 = cbs(in_, width[1], 1, 1)
         self.cbs3 = cbs(width[1], width[2], 3, 2)
         self.concat4 = concat(dim=1)
-        self.out_channels = width[0] + width[2]
 
     def _emit(self, pb, x, out=None):
         """`out`: optional pair of slices (pooled branch, strided branch) of a wider buffer."""
@@ -170,7 +176,6 @@ class sppcspc(_Block):  # in_ -> out_, same spatial size
         self.cbs9 = cbs(width[4], width[5], 3, 1)
         self.concat10 = concat(dim=1)
         self.cbs11 = cbs(width[0] + width[5], width[6], 1, 1)
-        self.out_channels = width[6]
 
     def _emit(self, pb, x, out=None):
         w3 = _w(self.cbs3)
@@ -216,16 +221,16 @@ class decode(torch.nn.Module):
 
     def __init__(self, args):
         super().__init__()
-        self.anchor_rel = args.anchor
-        self.anchor = args.input_size * torch.tensor(args.anchor)
+        self.anchor = args.input_size * torch.tensor(args.anchor)     # pixels; the kernels take these values
         self.input_size = args.input_size
         self.output_size = args.output_size
         self.output_layer = args.output_layer
         self.stride = [self.input_size / _ for _ in self.output_size]
+        self.sigmoid = torch.nn.Sigmoid()         # parameter-free; kept so module trees line up
 
     def forward(self, x):
         heads = [t.detach().float().contiguous() for t in x]
-        return _post.decode(heads, self.input_size, self.anchor_rel, deploy=False)
+        return _post.decode(heads, self.input_size, self.anchor, deploy=False)
 
 
 class deploy(torch.nn.Module):

@@ -167,7 +167,7 @@ class yolov7(torch.nn.Module):
         if not x.is_cuda:
             raise RuntimeError('objectdetection_amd runs on the GPU only (no CPU fallback)')
         if self.training:
-            raise RuntimeError('training forward is not part of this build yet: call model.eval()')
+            raise RuntimeError('head_tensors runs the inference plan: call model.eval() first (training goes through forward())')
         plan = self._plan(x, slot)
         plan.run(x.detach().float().contiguous())
         k = 5 + self.output_class
@@ -180,7 +180,7 @@ class yolov7(torch.nn.Module):
 
     def _decoded(self, x, deploy):
         heads = self.head_tensors(x)
-        y = _post.decode(heads, self.decode.input_size, self.decode.anchor_rel, deploy)
+        y = _post.decode(heads, self.decode.input_size, self.decode.anchor, deploy)
         return y if x.dtype == torch.float32 else y.to(x.dtype)
 
     def forward(self, x):
@@ -230,6 +230,12 @@ class yolov7(torch.nn.Module):
         state['_state'] = None
         state['_hook'] = None
         return state
+
+    def __setstate__(self, state):
+        """Unpickling (checkpoints pickle whole modules, train_class.py:262-276): the execution state is
+        rebuilt on first use; a checkpoint written by the reference has none of these attributes."""
+        super().__setstate__(state)
+        self.__dict__.update(_plans={}, _train_plans={}, _state=None, _hook=None)
 
 
 class _TrainForward(torch.autograd.Function):

@@ -21,10 +21,15 @@ def _ptr(t):
 
 
 def decode_desc(heads, input_size, anchor, deploy):
-    """Build an odamd_decode_desc for three raw head tensors (B, A, H, W, K) float32."""
+    """Build an odamd_decode_desc for three raw head tensors (B, A, H, W, K) float32.
+    `anchor`: the relative anchors of the args Namespace (nested tuples), or a tensor that already holds
+    them in pixels (`decode.anchor` = input_size * tensor(args.anchor), model/layer.py:266)."""
     d = _lib.DecodeDesc()
     b, a, _, _, k = heads[0].shape
-    anc = (input_size * torch.tensor(anchor, dtype=torch.float32)).tolist()   # model/layer.py:266
+    if torch.is_tensor(anchor):
+        anc = anchor.detach().float().cpu().tolist()
+    else:
+        anc = (input_size * torch.tensor(anchor, dtype=torch.float32)).tolist()   # model/layer.py:266
     for i, hd in enumerate(heads):
         if hd.dtype != torch.float32 or not hd.is_contiguous() or not hd.is_cuda:
             raise ValueError('head tensors must be contiguous float32 CUDA tensors')

@@ -84,7 +84,7 @@ class predict_class:
             if hasattr(self.model.model, 'head_tensors'):
                 heads = self._forward_heads(tensor)
                 dec = self.model.model.decode
-                res = _post.postprocess_heads([h[:1] for h in heads], dec.input_size, dec.anchor_rel,
+                res = _post.postprocess_heads([h[:1] for h in heads], dec.input_size, dec.anchor,
                                               self.confidence_threshold, self.iou_threshold, scale)
             else:
                 res = _post.postprocess(self.model(tensor)[:1].float(), self.confidence_threshold, self.iou_threshold,
@@ -102,7 +102,7 @@ class predict_class:
         with torch.no_grad():
             heads = self._forward_heads(tensor)
             dec = self.model.model.decode
-            res = _post.postprocess_heads(heads, dec.input_size, dec.anchor_rel, self.confidence_threshold,
+            res = _post.postprocess_heads(heads, dec.input_size, dec.anchor, self.confidence_threshold,
                                           self.iou_threshold, scale)
         return [r for r, _ in res.per_image()][:b]
 
@@ -118,50 +118,87 @@ class predict_class:
         return _post.nms_rows(p, self.iou_threshold).per_image()[0][0]
 
 
+class PostResultList:
+    """Results of the sub-batches of one `detect_pipeline.submit` call, in image order."""
+
+    def __init__(self, parts):
+        self.parts = parts
+        self.done = [p.done for p in parts]
+
+    @property
+    def count(self):
+        return torch.cat([p.count for p in self.parts])
+
+    @property
+    def cand(self):
+        return torch.cat([p.cand for p in self.parts])
+
+    def per_image(self):
+        out = []
+        for p in self.parts:
+            out.extend(p.per_image())
+        return out
+
+
 class detect_pipeline:
-    """Batched detection as a two-stage pipeline on two HIP streams: the network of batch i+1 runs
-    while batch i is decoded, filtered, sorted and NMS-ed (predict.py:67-92 per image).  The network
-    is HBM-bound and the NMS mask VALU-bound, so the stages overlap well.  Two network plans
-    alternate, so the heads a post-processing pass reads are not overwritten by the next forward.
+    """Batched detection as a pipeline on several HIP streams: the network of batch i+1 runs while
+    batch i is decoded, filtered, sorted and NMS-ed (predict.py:67-92 per image).  The network is
+    HBM-bound and the NMS mask VALU-bound, so the stages overlap well.  Two network plans alternate, so
+    the heads a post-processing pass reads are not overwritten by the next forward.
+
+    `splits` > 1 additionally cuts every batch into that many sub-batches (images are independent) that
+    run concurrently on their own streams: the launches of the small 40x40 / 20x20 maps are latency
+    bound and fill only part of the chip each, several of them in flight at different layers fill it.
 
         pipe = detect_pipeline(model, 0.5, 0.5)
         results = [pipe.submit(batch) for batch in batches]     # asynchronous
         pipe.synchronize()                                      # results' tensors are now final
     """
 
-    def __init__(self, model, confidence_threshold, iou_threshold, anchor=None, input_size=None):
+    def __init__(self, model, confidence_threshold, iou_threshold, anchor=None, input_size=None, splits=1):
         self.model = model
         self.conf, self.iou = confidence_threshold, iou_threshold
-        self.anchor = anchor if anchor is not None else model.decode.anchor_rel
+        self.anchor = anchor if anchor is not None else model.decode.anchor
         self.input_size = input_size if input_size is not None else model.decode.input_size
-        import os
-        pr = [int(v) for v in os.environ.get('ODAMD_PIPE_PRIO', '0,0').split(',')]
-        self.net_stream = torch.cuda.Stream(priority=pr[0])
-        self.post_stream = torch.cuda.Stream(priority=pr[1])
+        self.splits = splits
+        self.net_streams = [torch.cuda.Stream() for _ in range(splits)]
+        self.post_streams = [torch.cuda.Stream() for _ in range(splits)]
         self.slot = 0
-        self.heads_free = [None, None]      # event: post-processing has finished reading the slot's heads
+        self.heads_free = {}                # (slot, split) -> event: post-processing has finished reading those heads
 
     def submit(self, x, scale_xy=None):
-        """Enqueue one batch; returns its PostResult (device tensors, final once `result.done` has
-        completed or after `synchronize()`)."""
+        """Enqueue one batch; returns its result (device tensors, final once `result.done` has completed or
+        after `synchronize()`): a PostResult, or a PostResultList when splits > 1."""
         slot = self.slot
         self.slot ^= 1
-        self.net_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.net_stream):
-            if self.heads_free[slot] is not None:
-                self.net_stream.wait_event(self.heads_free[slot])
-            heads = self.model.head_tensors(x, slot=slot)
-            ready = torch.cuda.Event()
-            ready.record(self.net_stream)
-        with torch.cuda.stream(self.post_stream):
-            self.post_stream.wait_event(ready)
-            res = _post.postprocess_heads(heads, self.input_size, self.anchor, self.conf, self.iou, scale_xy)
-            done = torch.cuda.Event()
-            done.record(self.post_stream)
-        self.heads_free[slot] = done
-        res.done = done
-        return res
+        b = x.shape[0]
+        n = self.splits if b % self.splits == 0 else 1
+        hb = b // n
+        cur = torch.cuda.current_stream()
+        parts = []
+        for s in range(n):
+            xs = x if n == 1 else x[s * hb:(s + 1) * hb]
+            sc = None if scale_xy is None else scale_xy[s * hb:(s + 1) * hb]
+            net, post = self.net_streams[s], self.post_streams[s]
+            net.wait_stream(cur)
+            xs.record_stream(net)           # the caller may free x while the network still reads it
+            with torch.cuda.stream(net):
+                free = self.heads_free.get((slot, s))
+                if free is not None:
+                    net.wait_event(free)
+                heads = self.model.head_tensors(xs, slot=(slot, s))
+                ready = torch.cuda.Event()
+                ready.record(net)
+            with torch.cuda.stream(post):
+                post.wait_event(ready)
+                res = _post.postprocess_heads(heads, self.input_size, self.anchor, self.conf, self.iou, sc)
+                done = torch.cuda.Event()
+                done.record(post)
+            self.heads_free[(slot, s)] = done
+            res.done = done
+            parts.append(res)
+        return parts[0] if n == 1 else PostResultList(parts)
 
     def synchronize(self):
-        self.net_stream.synchronize()
-        self.post_stream.synchronize()
+        for st in self.net_streams + self.post_streams:
+            st.synchronize()

@@ -427,8 +427,9 @@ class train_class:
         recall and the reference's 'm_ap' = precision * recall (train_class.py:296-333)."""
         args = self.args
         with torch.no_grad():
+            # cached inference plans re-fold their weights by themselves when a training step has
+            # written the parameters (engine.touch_weights), so the model's own plan is reused
             model = self.ema.ema_model.eval() if self.ema else self.model.eval()
-            model._plans = {}       # inference plans hold folded copies of the weights: rebuild from the current ones
             loss_sum = torch.zeros((), device=args.device)
             counts = torch.zeros(3, dtype=torch.int64, device=args.device)
             steps = 0

@@ -48,6 +48,7 @@ class FlatState:
                 view.copy_(p.data.float())
                 p.data = view
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                p._odamd_flat = self                   # a block asked to train on its own finds its network's storage
         bufs = [b for b in model.buffers() if b.dtype.is_floating_point]
         self.buf_offsets, nb = {}, 0
         for b in bufs:
@@ -481,7 +482,13 @@ class TrainPlan:
             if slot is not None:
                 args[slot] = img
             check(fn(*args, stream), name)
-        self.state.counters.add_(1)          # every BatchNorm2d.num_batches_tracked (views of this vector)
+        if self.block:                       # a block of a larger network: only its own BatchNorm layers ran
+            for m in self.model.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.num_batches_tracked.add_(1)
+        else:
+            self.state.counters.add_(1)      # every BatchNorm2d.num_batches_tracked (views of this vector)
+        engine.touch_weights()               # BN running buffers were written through raw pointers
         if self.block:
             return self.out_nchw
         k = 5 + self.model.output_class
@@ -489,7 +496,7 @@ class TrainPlan:
                  for o in self.head_ops]
         self.heads = heads
         dec = self.model.decode
-        d = _post.decode_desc(heads, dec.input_size, dec.anchor_rel, False)
+        d = _post.decode_desc(heads, dec.input_size, dec.anchor, False)
         self.decode_desc = d
         check(lib.odamd_decode(C.byref(d), self.pred.data_ptr(), stream), 'decode')
         return self.pred
@@ -580,6 +587,7 @@ def optimizer_step(state, lr, weight_decay=0.0005, betas=(0.937, 0.999), eps=1e-
     """Adam with coupled L2 over the flat buffers, fused with the EMA of the parameters; the EMA
     of the BN running buffers follows in a second launch (train_class.py:211-213)."""
     state.step += 1
+    engine.touch_weights()                   # parameters are about to be written through raw pointers
     d = 0.0
     ema_ptr = None
     if ema and state.ema_param is not None:

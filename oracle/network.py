@@ -20,12 +20,21 @@ class Net:
     sd        : dict name -> tensor (parameters may require grad)
     training  : BN uses batch statistics and updates running buffers in `sd`
     taps      : optional dict filled with named intermediate activations
+    act_bf16  : round every cbs output to bf16 (straight-through gradient): emulates the storage
+                precision of the bf16 compute path, so that max-pool arg-max decisions are taken on the
+                values that path actually pools (float32 activations decide near-ties differently)
     """
 
-    def __init__(self, sd, training=False, taps=None):
+    def __init__(self, sd, training=False, taps=None, act_bf16=False):
         self.sd = sd
         self.training = training
         self.taps = taps
+        self.act_bf16 = act_bf16
+
+    def _q(self, x):
+        if not self.act_bf16:
+            return x
+        return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
 
     def _tap(self, name, x):
         if self.taps is not None:
@@ -42,7 +51,7 @@ class Net:
                          self.training, BN_MOMENTUM, BN_EPS)
         if self.training and (p + '.bn.num_batches_tracked') in self.sd:
             self.sd[p + '.bn.num_batches_tracked'] += 1
-        return self._tap(p, F.silu(y))
+        return self._tap(p, self._q(F.silu(y)))
 
     def _chain(self, p, x):
         i = 0
@@ -150,9 +159,9 @@ def deploy_sigmoid(pred):
     return torch.cat([pred[..., :4], torch.sigmoid(pred[..., 4:])], -1)
 
 
-def yolov7_forward(sd, x, args, training=False, deploy=False, taps=None):
+def yolov7_forward(sd, x, args, training=False, deploy=False, taps=None, act_bf16=False):
     """Whole reference forward on CPU: trunk -> decode (-> deploy sigmoid)."""
-    net = Net(sd, training, taps)
+    net = Net(sd, training, taps, act_bf16)
     heads = net.trunk(x, args.output_class, args.output_layer[0])
     out = decode(heads, args.input_size, args.anchor)
     return deploy_sigmoid(out) if deploy else out

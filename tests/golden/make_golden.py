@@ -22,18 +22,23 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = '/root/reference'
-sys.path.insert(0, ROOT)
+# The reference's `model` directory has no __init__.py (a namespace package), and this repository ships a
+# regular package of the same name (the import-path alias of the MI355X classes) that would win over it:
+# import the reference first, with only its own tree on the path.
 sys.path.insert(0, REF)
 for name in ('cv2', 'wandb', 'torchvision'):
     sys.modules.setdefault(name, types.ModuleType(name))
 _ARGV = list(sys.argv)
 sys.argv = ['make_golden']
 
-from oracle import patterns  # noqa: E402
 import model.layer as ref_layer  # noqa: E402
 from model.yolov7 import yolov7 as ref_yolov7  # noqa: E402
 import predict as ref_predict  # noqa: E402
 import train_class as ref_train  # noqa: E402
+
+assert ref_layer.__file__.startswith(REF), ref_layer.__file__
+sys.path.insert(1, ROOT)
+from oracle import patterns  # noqa: E402
 
 torch.set_num_threads(4)
 f32 = np.float32
@@ -339,7 +344,33 @@ def gen_pruned():
     save('pruned.npz', widths=np.asarray(widths), cfg=np.asarray(cfg), keys=np.asarray(keys), shapes=shapes, eval=y)
 
 
+def gen_ckpt():
+    """A checkpoint file exactly as the reference writes it (train_class.py:262-276: torch.save of a dict whose
+    'model' entry is the pickled module object, class paths model.yolov7.yolov7 / model.layer.*), for a small
+    pruned configuration so that the file stays small, plus the reference's own eval output for it."""
+    args = patterns.default_args(input_size=64, output_class=3)
+    std = ref_yolov7(args)
+    widths = [m.conv.out_channels for m in std.modules() if isinstance(m, ref_layer.cbs)]
+    cfg = [max(6, w // 6 + (i % 4)) for i, w in enumerate(widths)]
+    net = ref_yolov7(args, config=cfg)
+    patterns.fill_state_dict(net)
+    net.eval()
+    x = patterns.image_batch(2, 64)
+    with torch.no_grad():
+        y = net(x).numpy()
+        yd = ref_layer.deploy(net)(x).numpy()
+    model_dict = {'model': net, 'epoch_finished': 3, 'optimizer_state_dict': None, 'ema_update': 0, 'standard': 0.5,
+                  'train_loss': 1.0, 'val_loss': 1.0, 'val_m_ap': 0.5}
+    path = os.path.join(HERE, 'ref_ckpt.pt')
+    torch.save(model_dict, path)
+    print(f'ref_ckpt.pt: {os.path.getsize(path) / 1024:.1f} KiB')
+    save('ref_ckpt.npz', cfg=np.asarray(cfg), eval=y, deploy=yd)
+
+
 if __name__ == '__main__':
+    if len(_ARGV) > 1 and _ARGV[1] == 'ckpt':
+        gen_ckpt()
+        sys.exit(0)
     if len(_ARGV) > 1 and _ARGV[1] == 'net128':
         gen_net128()
         sys.exit(0)
@@ -353,3 +384,4 @@ if __name__ == '__main__':
     gen_nms()
     gen_training()
     gen_pruned()
+    gen_ckpt()

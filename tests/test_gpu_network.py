@@ -18,6 +18,13 @@ def rel_err(got, ref):
     return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
 
 
+def assert_elementwise(got, ref, tol):
+    """Every element on its own: |got - ref| <= tol * |ref| + tol * max|ref| (the max-norm check alone
+    would let small-magnitude outputs be arbitrarily wrong)."""
+    ref = np.asarray(ref)
+    np.testing.assert_allclose(np.asarray(got), ref, rtol=tol, atol=tol * float(np.abs(ref).max()))
+
+
 @pytest.fixture(scope='module')
 def od():
     import objectdetection_amd.engine as engine
@@ -40,6 +47,15 @@ BLOCK_CASES = [
     ('cbs', dict(in_=64, out_=160, kernel_size=3, stride=2), (1, 64, 20, 20)),
     ('cbs', dict(in_=128, out_=64, kernel_size=1, stride=1), (2, 128, 33, 17)),
     ('cbs', dict(in_=48, out_=80, kernel_size=3, stride=1), (1, 48, 20, 20)),
+    # deep layers on small maps: the LDS-DMA kernel (fragment-ordered weights), whole and ragged channel
+    # blocks, ragged tiles, 1x1 over a pixel count that is no multiple of the tile
+    ('cbs', dict(in_=128, out_=128, kernel_size=3, stride=1), (2, 128, 20, 20)),
+    ('cbs', dict(in_=64, out_=64, kernel_size=3, stride=1), (2, 64, 40, 40)),
+    ('cbs', dict(in_=80, out_=100, kernel_size=3, stride=1), (3, 80, 13, 27)),
+    ('cbs', dict(in_=256, out_=128, kernel_size=3, stride=1), (1, 256, 20, 20)),
+    ('cbs', dict(in_=512, out_=256, kernel_size=1, stride=1), (4, 512, 20, 20)),
+    ('cbs', dict(in_=256, out_=136, kernel_size=1, stride=1), (3, 256, 19, 21)),
+    ('cbs', dict(in_=1024, out_=256, kernel_size=1, stride=1), (2, 1024, 20, 20)),
     # >= 32768 pixels: the persistent streaming 1x1 kernel (ragged last tile, 1..2 channel blocks, partial chunk)
     ('cbs', dict(in_=64, out_=32, kernel_size=1, stride=1), (2, 64, 128, 128)),
     ('cbs', dict(in_=128, out_=128, kernel_size=1, stride=1), (2, 128, 128, 130)),
@@ -70,6 +86,7 @@ def test_block_forward(od, kind, kw, shape, dtype):
         got = mod.cuda().eval()(x.cuda()).cpu().numpy()
         assert got.shape == ref.shape
         assert rel_err(got, ref) < TOL[dtype], (kind, kw, rel_err(got, ref))
+        assert_elementwise(got, ref, TOL[dtype])
     finally:
         engine.set_compute_dtype(None)
 
@@ -90,11 +107,13 @@ def test_block_golden_f32(od, golden):
         patterns.fill_state_dict(mod)
         got = mod.cuda().eval()(patterns.wave(xn, shape, 1.0).cuda()).cpu().numpy()
         assert rel_err(got, g[f'{tag}.eval']) < TOL['f32'], (tag, rel_err(got, g[f'{tag}.eval']))
+        assert_elementwise(got, g[f'{tag}.eval'], TOL['f32'])
     hd = layer.head(16, 12, 3)
     patterns.fill_state_dict(hd)
     got = hd.cuda().eval()(patterns.wave('x16', (2, 16, 12, 12), 1.0).cuda()).cpu().numpy()
     assert got.shape == g['head.eval'].shape
     assert rel_err(got, g['head.eval']) < TOL['f32']
+    assert_elementwise(got, g['head.eval'], TOL['f32'])
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
@@ -115,8 +134,11 @@ def test_whole_network_vs_reference_fixture(od, golden, dtype):
             # boxes (pixels) and logits have different scales: check them separately
             assert rel_err(got[..., :4], ref[..., :4]) < TOL[dtype], rel_err(got[..., :4], ref[..., :4])
             assert rel_err(got[..., 4:], ref[..., 4:]) < TOL[dtype], rel_err(got[..., 4:], ref[..., 4:])
+            assert_elementwise(got[..., :4], ref[..., :4], TOL[dtype])
+            assert_elementwise(got[..., 4:], ref[..., 4:], TOL[dtype])
             dep = layer.deploy(net)(x).cpu().numpy()
             assert rel_err(dep[..., 4:], g[f'{tag}.deploy'][..., 4:]) < TOL[dtype]
+            assert_elementwise(dep[..., 4:], g[f'{tag}.deploy'][..., 4:], TOL[dtype])
     finally:
         engine.set_compute_dtype(None)
 

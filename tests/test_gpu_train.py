@@ -134,6 +134,9 @@ def _oracle_f64_step(tag, size, ncls, batch, g, net):
     return pred.detach().numpy(), {k: v.grad.numpy() for k, v in sd.items() if getattr(v, 'requires_grad', False)}
 
 
+NOISE_FACTOR = 3      # GPU error vs fp64 <= NOISE_FACTOR x the reference fixture's own error vs fp64 (+ 1e-4)
+
+
 @pytest.mark.parametrize('tag,size,ncls,batch,fname', [('s128', 128, 5, 4, 'net128.npz')])
 def test_whole_network_train_step_matches_reference(te, golden, tag, size, ncls, batch, fname):
     """Forward (train-mode BN), loss and backward of the whole network.
@@ -142,7 +145,7 @@ def test_whole_network_train_step_matches_reference(te, golden, tag, size, ncls,
     1e-4 (forward) and 1e-3..1e-2 (early-layer gradients): its fixture differs from an fp64
     evaluation of the same step by that much, and so does a 1-thread rerun of torch.  The bar here
     is therefore "as close to the fp64 truth as the reference is": every GPU error against the fp64
-    oracle must stay within 10x the reference fixture's own error (+1e-4; both are single draws of
+    oracle must stay within NOISE_FACTOR (3) x the reference fixture's own error (+1e-4; both are single draws of
     rounding noise that the network amplifies).  The per-block tests above pin the kernels at 1e-4
     against the reference directly.  (The 64x64 fixture is not used here: its deepest maps are 2x2,
     so BatchNorm runs over 8 values per channel and the step is too ill-conditioned to compare.)"""
@@ -166,7 +169,7 @@ def test_whole_network_train_step_matches_reference(te, golden, tag, size, ncls,
         e_gpu, e_ref = rel_err(pred[..., sl], p64[..., sl]), rel_err(ref[..., sl], p64[..., sl])
         fwd_noise = max(fwd_noise, e_gpu, e_ref)
         print(tag, 'forward', what, 'gpu-vs-f64', e_gpu, 'reference-vs-f64', e_ref)
-        assert e_gpu <= 10 * e_ref + 1e-4, what
+        assert e_gpu <= NOISE_FACTOR * e_ref + 1e-4, what
     screen = [torch.from_numpy(g[f'{tag}.screen{b}']) for b in range(batch)]
     lab = torch.from_numpy(g[f'{tag}.label'])
     loss = plan.loss(screen, lab, 0.01).cpu().numpy()
@@ -181,16 +184,60 @@ def test_whole_network_train_step_matches_reference(te, golden, tag, size, ncls,
             n = key[len(tag) + 6:]
             e_gpu, e_ref = rel_err(params[n].grad.cpu().numpy(), g64[n]), rel_err(g[key], g64[n])
             print(tag, 'grad', n, 'gpu-vs-f64', e_gpu, 'reference-vs-f64', e_ref)
-            assert e_gpu <= 10 * e_ref + 1e-4, n
+            assert e_gpu <= NOISE_FACTOR * e_ref + 1e-4, n
         elif key.startswith(f'{tag}.buf.'):
             n = key[len(tag) + 5:]
             assert rel_err(dict(net.named_buffers())[n].cpu().numpy(), g[key]) < 1e-4, n
-    # every parameter: gradient norm against fp64, within 10x the worst reference deviation
+    # every parameter: gradient norm against fp64, within NOISE_FACTOR x the worst reference deviation
     worst_ref = max(abs(g[k][0] - np.linalg.norm(g64[k[len(tag) + 7:]].ravel())) /
                     (np.linalg.norm(g64[k[len(tag) + 7:]].ravel()) + 1e-30) for k in g.files if k.startswith(f'{tag}.gnorm.'))
     worst_gpu = max(rel_err(p.grad.cpu().numpy(), g64[n]) for n, p in params.items())
     print(tag, 'all parameters: worst gpu gradient error vs f64', worst_gpu, ' worst reference norm error', worst_ref)
-    assert worst_gpu <= 10 * worst_ref + 1e-4
+    assert worst_gpu <= NOISE_FACTOR * worst_ref + 1e-4
+
+
+def test_whole_network_train_step_bf16(te, golden):
+    """bf16 mixed-precision step of the whole network (128 x 128, batch 4, the labels of net128.npz) against the
+    fp64 oracle of the same step: forward 2e-2, loss 2e-2, every parameter gradient by direction (cosine)
+    and size (norm ratio)."""
+    from objectdetection_amd.model.yolov7 import yolov7
+    from objectdetection_amd.engine import BF16
+    tag, size, ncls, batch = 's128', 128, 5, 4
+    g = golden('net128.npz')
+    args = patterns.default_args(input_size=size, output_class=ncls)
+    net = yolov7(args)
+    patterns.fill_state_dict(net)
+    p64, g64 = _oracle_f64_step(tag, size, ncls, batch, g, net)
+    net = net.cuda().train()
+    state = te.FlatState(net)
+    plan = te.TrainPlan(net, state, batch, size, dtype=BF16)
+    x = patterns.image_batch(batch, size).cuda()
+    pred = plan.forward(x).cpu().numpy()
+    for sl, what in ((slice(0, 4), 'boxes'), (slice(4, None), 'logits')):
+        e = rel_err(pred[..., sl], p64[..., sl])
+        print('bf16 forward', what, e)
+        assert e < 2e-2, (what, e)
+    screen = [torch.from_numpy(g[f'{tag}.screen{b}']) for b in range(batch)]
+    loss = plan.loss(screen, torch.from_numpy(g[f'{tag}.label']), 0.01).cpu().numpy()
+    print('bf16 loss', loss, g[f'{tag}.loss'])
+    np.testing.assert_allclose(loss, g[f'{tag}.loss'], rtol=2e-2)
+    state.grad.zero_()
+    plan.backward(x)
+    torch.cuda.synchronize()
+    worst_cos, worst_norm = (1.0, ''), (0.0, '')
+    for n, p in net.named_parameters():
+        a, r = p.grad.double().cpu().numpy().ravel(), g64[n].ravel()
+        na, nr = np.linalg.norm(a), np.linalg.norm(r)
+        cos = float(a @ r / (na * nr + 1e-300))
+        ratio = abs(na / (nr + 1e-300) - 1.0)
+        worst_cos = min(worst_cos, (cos, n))
+        worst_norm = max(worst_norm, (ratio, n))
+    print('bf16 whole-network gradients: worst cosine', worst_cos, ' worst norm deviation', worst_norm)
+    assert worst_cos[0] >= BF16_GRAD_COS, worst_cos
+    assert worst_norm[0] <= BF16_GRAD_NORM, worst_norm
+
+
+BF16_GRAD_COS, BF16_GRAD_NORM = 0.99, 0.05
 
 
 @pytest.mark.parametrize('cin,cout,k,s,h,w,b', [
@@ -266,8 +313,9 @@ def test_conv_wgrad_dtypes(cin, cout, k, s, h, w, b, dtype):
     assert float((dw.cpu().double() - ref).abs().max()) <= 4e-5 * float(ref.abs().max())
 
 
-def _oracle_block_train(kind, mod, x, gy):
-    """float32 CPU autograd of one block in train mode: output, dx, parameter gradients."""
+def _oracle_block_train(kind, mod, x, gy, act_bf16=False):
+    """float32 CPU autograd of one block in train mode: output, dx, parameter gradients.  act_bf16: block
+    activations rounded to bf16 (what the bf16 path pools), gradients straight through."""
     from oracle import network
     sd = {}
     for key, v in mod.state_dict().items():
@@ -275,7 +323,7 @@ def _oracle_block_train(kind, mod, x, gy):
         if t.dtype.is_floating_point and key.endswith(('weight', 'bias')):
             t.requires_grad_(True)
         sd['.' + key] = t
-    net = network.Net(sd, training=True)
+    net = network.Net(sd, training=True, act_bf16=act_bf16)
     xr = x.clone().requires_grad_(True)
     y = net.cbs('', xr, mod.conv.stride[0]) if kind == 'cbs' else getattr(net, kind)('', xr)
     y.backward(gy)
@@ -317,6 +365,7 @@ def test_block_train_step_bf16(te, kind, kw, shape):
               else getattr(network.Net(sd0, training=True), kind)('', x))
     gy = torch.randn(y0.shape, generator=g)
     y_ref, dx_ref, grads = _oracle_block_train(kind, mod, x, gy)
+    _, dx_q, grads_q = _oracle_block_train(kind, mod, x, gy, act_bf16=True)
     mod = mod.cuda().train()
     state = te.FlatState(mod)
     plan = te.TrainPlan(mod, state, shape[0], shape[2], dtype=BF16, block_input=shape[1:])
@@ -330,15 +379,25 @@ def test_block_train_step_bf16(te, kind, kw, shape):
     for n, p in mod.named_parameters():
         pairs[n] = (p.grad.cpu(), grads[n])
     if kind in ('mp', 'sppcspc'):
-        # Max-pool backward sends a window's gradient to its arg-max.  bf16 activations turn near-ties
-        # into ties or flip them, so a few windows route their gradient to a neighbouring pixel (the
-        # 13x13 windows of sppcspc share maxima, so one flip moves a lot); that is a property of pooling
-        # low-precision activations, not of the kernels (test_pool_backward_kernels_with_ties pins them
-        # exactly).  The bar for these two blocks is the direction of every gradient tensor.
-        cos = {k2: float(torch.nn.functional.cosine_similarity(a.flatten().double(), r.flatten().double(), dim=0))
-               for k2, (a, r) in pairs.items()}
-        bad = {k2: v for k2, v in cos.items() if not v > 0.9}
-        assert not bad, (bad, min(cos.values()))
+        # Max-pool backward sends a window's gradient to its arg-max.  bf16 activations turn float32
+        # near-ties into ties or flip them, so against the float32 oracle a few windows route their gradient
+        # to a neighbouring pixel (a property of pooling low-precision activations, not of the kernels:
+        # test_pool_backward_kernels_with_ties pins those exactly).  The comparison is therefore tie-aware: the
+        # oracle pools the same bf16-rounded activations the kernels pool (act_bf16), which leaves only the
+        # windows whose two largest values differ by the last bf16 bit; the bar is every tensor's direction
+        # and size.  Against the plain float32 oracle the direction alone is checked, loosely.
+        refs = dict(grads_q, dx=dx_q)
+        cos_q, cos_f, nrm = {}, {}, {}
+        for k2, (a, r) in pairs.items():
+            rq = refs[k2]
+            cos_q[k2] = float(torch.nn.functional.cosine_similarity(a.flatten().double(), rq.flatten().double(), dim=0))
+            cos_f[k2] = float(torch.nn.functional.cosine_similarity(a.flatten().double(), r.flatten().double(), dim=0))
+            nrm[k2] = abs(float(a.double().norm() / rq.double().norm()) - 1.0)
+        print(kind, 'bf16 pool block: min cosine vs bf16-activation oracle', min(cos_q.values()), 'vs f32 oracle',
+              min(cos_f.values()), 'max norm deviation', max(nrm.values()))
+        bad = {k2: (cos_q[k2], nrm[k2]) for k2 in pairs if not (cos_q[k2] > 0.99 and nrm[k2] < 0.05)}
+        assert not bad, bad
+        assert min(cos_f.values()) > 0.9, cos_f
     else:
         # conv-only blocks: 2e-2 for the data gradient; parameter gradients are sums of such terms over
         # all pixels behind up to six bf16 layers: 5e-2

@@ -192,3 +192,42 @@ def test_other_presets_train_step(preset, amp):
     again = tc.train_step(image, screen, expend).cpu().numpy()
     assert np.isfinite(again).all()
     assert torch.isfinite(tc.model.train_state().param).all()
+
+
+def test_cached_eval_plan_follows_training_steps():
+    """eval forward -> train_step -> eval forward: the optimizer and the train-mode BatchNorm write
+    parameters and running buffers through raw pointers, which tensor `_version`s do not see; the cached
+    inference plan must still run on the updated weights (compared with the oracle on the new state_dict)."""
+    from objectdetection_amd.train_class import train_class, synthetic_dataset
+    args = _args(lr_start=0.01)
+    torch.manual_seed(11)
+    tc = train_class(args)
+    model = tc.model
+    patterns.fill_state_dict(model)
+    ds = synthetic_dataset(args, 8)
+    image, screen, expend, _ = ds.collate_fn([ds[i] for i in range(4)])
+    x = image.cuda()
+
+    def oracle_eval():
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            return network.yolov7_forward(sd, image, args).numpy()
+
+    def check():
+        model.eval()
+        with torch.no_grad():
+            got = model(x).cpu().numpy()
+        ref = oracle_eval()
+        for sl in (slice(0, 4), slice(4, None)):
+            err = np.abs(got[..., sl] - ref[..., sl]).max() / np.abs(ref[..., sl]).max()
+            assert err < 1e-4, err
+        return got
+
+    before = check()
+    plans = dict(model._plans)
+    model.train()
+    for _ in range(3):
+        tc.train_step(image, screen, expend)
+    after = check()
+    assert model._plans.keys() == plans.keys() and all(model._plans[k] is plans[k] for k in plans)   # same cached plan
+    assert np.abs(after - before).max() > 1e-3 * np.abs(before).max()       # the weights did move
