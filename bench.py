@@ -92,7 +92,8 @@ def train_leg(a, dev, rank, world, dist, steps, warmup, amp=False):
     tc.optimizer.ema = True                      # every rank carries the EMA so that ranks do equal work
     tc.model.train_state().enable_ema()
     tc.model.train()
-    image = batch[0].to(dev)
+    image = batch[0].pin_memory().to(dev, non_blocking=True)     # page-locked source: an asynchronous copy on the
+    torch.cuda.current_stream().synchronize()                    # current stream, not a blocking default-stream one
     screen, expend = batch[1], batch[2]
 
     def fence():
@@ -289,10 +290,11 @@ def main():
         import threading
 
         def bail():
+            # the inference line is still printed, but a stalled training leg is a failure of the run
             if rank == 0:
                 out['train'] = {'error': 'training leg did not finish within 240 s'}
                 print(json.dumps(out), flush=True)
-            os._exit(0 if rank == 0 else 1)
+            os._exit(3)
         guard = threading.Timer(240.0, bail)
         guard.daemon = True
         guard.start()

@@ -72,9 +72,12 @@ template <> struct Vec<ODAMD_DTYPE_BF16> {
 // ------------------------------------------------------------------------------------------
 template <int DT, int MODE>
 __global__ void __launch_bounds__(256)
-channel_reduce_kernel(const char* __restrict__ y, int y_ld, const char* __restrict__ dact, int d_ld, size_t npix, int C,
+channel_reduce_kernel(const char* __restrict__ y, int y_ld, const char* __restrict__ dact, int d_ld, size_t npix, int Creal,
                       int vecs, int rows, const float* __restrict__ scale, const float* __restrict__ shift,
                       const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ part) {
+    // The tensors hold whole 16-byte channel vectors; Creal channels are real, the rest of the last vector is
+    // zero padding (irregular, pruned widths).  The partial table is laid out for the padded count C.
+    const int C = vecs * Vec<DT>::N;
     constexpr int N = Vec<DT>::N, ES = Vec<DT>::ES;
     extern __shared__ __attribute__((aligned(16))) float red[];   // [rows][vecs][2][N]
     const int v = threadIdx.x % vecs, r = threadIdx.x / vecs;
@@ -85,7 +88,10 @@ channel_reduce_kernel(const char* __restrict__ y, int y_ld, const char* __restri
     for (int e = 0; e < N; ++e) {
         s0[e] = 0.f; s1[e] = 0.f;
         const int c = v * N + e;
-        if (MODE == 1) { sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c]; }
+        if (MODE == 1) {
+            const bool real = c < Creal;
+            sc[e] = real ? scale[c] : 0.f; sh[e] = real ? shift[c] : 0.f; mu[e] = real ? mean[c] : 0.f; is[e] = real ? invstd[c] : 0.f;
+        }
     }
     // MODE 0 sums (y - pivot) and (y - pivot)^2 with pivot = the channel's value at pixel 0: the
     // variance then comes from numbers of the size of the spread, not of the mean (no cancellation)
@@ -168,8 +174,8 @@ channel_reduce_kernel(const char* __restrict__ y, int y_ld, const char* __restri
 // buffers updated with momentum and the unbiased variance, affine folded to (scale, shift).
 // One wave per channel: the lanes stride over the partial blocks and a butterfly of double adds
 // folds them (fixed order: the result does not depend on scheduling).
-__device__ __forceinline__ void fold_partials(const double* __restrict__ part, int nblk, int C, int c, double& s, double& q,
-                                              bool second) {
+__device__ __forceinline__ void fold_partials(const double* __restrict__ part, int nblk, int C /* padded: table stride */, int c,
+                                              double& s, double& q, bool second) {
     const int lane = threadIdx.x & 63;
     s = 0.0; q = 0.0;
     for (int b = lane; b < nblk; b += 64) {
@@ -184,18 +190,18 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ part, i
 }
 
 __global__ void __launch_bounds__(256)
-bn_stats_finalize_kernel(const double* __restrict__ part, int nblk, int C, double npix, const float* gamma,
+bn_stats_finalize_kernel(const double* __restrict__ part, int nblk, int C, int Cp, double npix, const float* gamma,
                          const float* beta, float eps, float momentum, float* running_mean,
                          float* running_var, float* mean, float* invstd, float* scale, float* shift) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     double s, q;
-    fold_partials(part, nblk, C, c, s, q, true);
+    fold_partials(part, nblk, Cp, c, s, q, true);
     if ((threadIdx.x & 63) != 0) return;
     const double md = s / npix;                    // mean of (y - pivot)
     double var = q / npix - md * md;
     if (var < 0.0) var = 0.0;
-    const double m = part[(size_t)nblk * 2 * C + c] + md;
+    const double m = part[(size_t)nblk * 2 * Cp + c] + md;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     mean[c] = (float)m;
     invstd[c] = is;
@@ -212,12 +218,12 @@ bn_stats_finalize_kernel(const double* __restrict__ part, int nblk, int C, doubl
 // Backward finalize: dgamma, dbeta (accumulated into the parameter gradients) and the two
 // per-channel means the apply pass needs.
 __global__ void __launch_bounds__(256)
-bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, int C, double npix, float* dgamma,
+bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, int C, int Cp, double npix, float* dgamma,
                        float* dbeta, float* mean_dz, float* mean_dzx) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     double s, q;
-    fold_partials(part, nblk, C, c, s, q, true);
+    fold_partials(part, nblk, Cp, c, s, q, true);
     if ((threadIdx.x & 63) != 0) return;
     dbeta[c] += (float)s;
     dgamma[c] += (float)q;
@@ -226,11 +232,11 @@ bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, int C, double 
 }
 
 __global__ void __launch_bounds__(256)
-bias_grad_finalize_kernel(const double* __restrict__ part, int nblk, int C, float* dbias) {
+bias_grad_finalize_kernel(const double* __restrict__ part, int nblk, int C, int Cp, float* dbias) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     double s, q;
-    fold_partials(part, nblk, C, c, s, q, false);
+    fold_partials(part, nblk, Cp, c, s, q, false);
     if ((threadIdx.x & 63) != 0) return;
     dbias[c] += (float)s;
 }
@@ -242,13 +248,16 @@ bias_grad_finalize_kernel(const double* __restrict__ part, int nblk, int C, floa
 template <int DT>
 __global__ void __launch_bounds__(256)
 bn_apply_silu_kernel(const char* __restrict__ y, int y_ld, char* __restrict__ out, int o_ld, size_t npix, int vecs, int rows,
-                     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean) {
+                     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean, int C) {
     constexpr int N = Vec<DT>::N, ES = Vec<DT>::ES;
     const int v = threadIdx.x % vecs, r = threadIdx.x / vecs;
     if (r >= rows) return;
     float sc[N], sh[N], mu[N];
 #pragma unroll
-    for (int e = 0; e < N; ++e) { sc[e] = scale[v * N + e]; sh[e] = shift[v * N + e]; mu[e] = mean[v * N + e]; }
+    for (int e = 0; e < N; ++e) {     // padding channels of the last vector: scale 0, shift 0 -> silu(0) = 0 stays 0
+        const int c = v * N + e;
+        sc[e] = c < C ? scale[c] : 0.f; sh[e] = c < C ? shift[c] : 0.f; mu[e] = c < C ? mean[c] : 0.f;
+    }
     const size_t step = (size_t)gridDim.x * rows;
     for (size_t pb = (size_t)blockIdx.x * rows + r; pb < npix; pb += 4 * step) {
         float a[4][N];
@@ -275,15 +284,17 @@ __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(char* __restrict__ y, int y_ld, const char* __restrict__ dact, int d_ld, size_t npix, int vecs, int rows,
                     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
                     const float* __restrict__ invstd, const float* __restrict__ mean_dz,
-                    const float* __restrict__ mean_dzx) {
+                    const float* __restrict__ mean_dzx, int C) {
     constexpr int N = Vec<DT>::N, ES = Vec<DT>::ES;
     const int v = threadIdx.x % vecs, r = threadIdx.x / vecs;
     if (r >= rows) return;
     float sc[N], sh[N], mu[N], is[N], mdz[N], mdx[N];
 #pragma unroll
-    for (int e = 0; e < N; ++e) {
+    for (int e = 0; e < N; ++e) {     // padding channels: scale 0 -> their gradient stays 0
         const int c = v * N + e;
-        sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c]; mdz[e] = mean_dz[c]; mdx[e] = mean_dzx[c];
+        const bool real = c < C;
+        sc[e] = real ? scale[c] : 0.f; sh[e] = real ? shift[c] : 0.f; mu[e] = real ? mean[c] : 0.f;
+        is[e] = real ? invstd[c] : 0.f; mdz[e] = real ? mean_dz[c] : 0.f; mdx[e] = real ? mean_dzx[c] : 0.f;
     }
     const size_t step = (size_t)gridDim.x * rows;
     for (size_t pb = (size_t)blockIdx.x * rows + r; pb < npix; pb += 2 * step) {
@@ -988,8 +999,8 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const PackDesc* __res
 
 int red_geometry(int C, int dtype, int* vecs, int* rows) {
     const int per = dtype == ODAMD_DTYPE_F32 ? 4 : 8;
-    if (C % per) return ODAMD_E_ALIGN;
-    *vecs = C / per;
+    if (C < 1) return ODAMD_E_ARG;
+    *vecs = (C + per - 1) / per;          // the tensors hold whole 16-byte vectors; a ragged tail is zero padding
     if (*vecs > 256) return ODAMD_E_SHAPE;
     *rows = 256 / *vecs;
     return ODAMD_OK;
@@ -1100,7 +1111,10 @@ void wgrad_launch(const WgradPlan& o, hipStream_t st) {
 
 extern "C" {
 
-size_t odamd_bn_workspace_bytes(int channels) { return ((size_t)RED_MAX_BLOCKS * 2 + 1) * channels * sizeof(double); }
+size_t odamd_bn_workspace_bytes(int channels) {
+    const int padded = (channels + 7) & ~7;       // the partial table is laid out for whole 16-byte vectors
+    return ((size_t)RED_MAX_BLOCKS * 2 + 1) * padded * sizeof(double);
+}
 
 int odamd_bn_train_forward(const void* y, int y_ld, void* out, int out_ld, size_t npix, int channels, const float* gamma,
                            const float* beta, float eps, float momentum, float* running_mean, float* running_var,
@@ -1121,11 +1135,11 @@ int odamd_bn_train_forward(const void* y, int y_ld, void* out, int out_ld, size_
         channel_reduce_kernel<ODAMD_DTYPE_F32, 0><<<nblk, vecs * rows, lds, st>>>((const char*)y, y_ld, nullptr, 0, npix, channels, vecs, rows, nullptr, nullptr, nullptr, nullptr, part);
     else
         channel_reduce_kernel<ODAMD_DTYPE_BF16, 0><<<nblk, vecs * rows, lds, st>>>((const char*)y, y_ld, nullptr, 0, npix, channels, vecs, rows, nullptr, nullptr, nullptr, nullptr, part);
-    bn_stats_finalize_kernel<<<(channels + 3) / 4, 256, 0, st>>>(part, nblk, channels, (double)npix, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+    bn_stats_finalize_kernel<<<(channels + 3) / 4, 256, 0, st>>>(part, nblk, channels, vecs * per, (double)npix, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
     if (dtype == ODAMD_DTYPE_F32)
-        bn_apply_silu_kernel<ODAMD_DTYPE_F32><<<ew_rows_grid(npix, rows), vecs * rows, 0, st>>>((const char*)y, y_ld, (char*)out, out_ld, npix, vecs, rows, scale, shift, mean);
+        bn_apply_silu_kernel<ODAMD_DTYPE_F32><<<ew_rows_grid(npix, rows), vecs * rows, 0, st>>>((const char*)y, y_ld, (char*)out, out_ld, npix, vecs, rows, scale, shift, mean, channels);
     else
-        bn_apply_silu_kernel<ODAMD_DTYPE_BF16><<<ew_rows_grid(npix, rows), vecs * rows, 0, st>>>((const char*)y, y_ld, (char*)out, out_ld, npix, vecs, rows, scale, shift, mean);
+        bn_apply_silu_kernel<ODAMD_DTYPE_BF16><<<ew_rows_grid(npix, rows), vecs * rows, 0, st>>>((const char*)y, y_ld, (char*)out, out_ld, npix, vecs, rows, scale, shift, mean, channels);
     return (int)hipGetLastError();
 }
 
@@ -1148,11 +1162,11 @@ int odamd_bn_silu_backward(void* y_dy, int y_ld, const void* dact, int dact_ld, 
         channel_reduce_kernel<ODAMD_DTYPE_F32, 1><<<nblk, vecs * rows, lds, st>>>((const char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, channels, vecs, rows, scale, shift, mean, invstd, part);
     else
         channel_reduce_kernel<ODAMD_DTYPE_BF16, 1><<<nblk, vecs * rows, lds, st>>>((const char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, channels, vecs, rows, scale, shift, mean, invstd, part);
-    bn_bwd_finalize_kernel<<<(channels + 3) / 4, 256, 0, st>>>(part, nblk, channels, (double)npix, dgamma, dbeta, mean_dz, mean_dzx);
+    bn_bwd_finalize_kernel<<<(channels + 3) / 4, 256, 0, st>>>(part, nblk, channels, vecs * per, (double)npix, dgamma, dbeta, mean_dz, mean_dzx);
     if (dtype == ODAMD_DTYPE_F32)
-        bn_bwd_apply_kernel<ODAMD_DTYPE_F32><<<ew_rows_grid(npix, rows), vecs * rows, 0, st>>>((char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, vecs, rows, scale, shift, mean, invstd, mean_dz, mean_dzx);
+        bn_bwd_apply_kernel<ODAMD_DTYPE_F32><<<ew_rows_grid(npix, rows), vecs * rows, 0, st>>>((char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, vecs, rows, scale, shift, mean, invstd, mean_dz, mean_dzx, channels);
     else
-        bn_bwd_apply_kernel<ODAMD_DTYPE_BF16><<<ew_rows_grid(npix, rows), vecs * rows, 0, st>>>((char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, vecs, rows, scale, shift, mean, invstd, mean_dz, mean_dzx);
+        bn_bwd_apply_kernel<ODAMD_DTYPE_BF16><<<ew_rows_grid(npix, rows), vecs * rows, 0, st>>>((char*)y_dy, y_ld, (const char*)dact, dact_ld, npix, vecs, rows, scale, shift, mean, invstd, mean_dz, mean_dzx, channels);
     return (int)hipGetLastError();
 }
 
@@ -1173,7 +1187,7 @@ int odamd_bias_grad(const void* dy, int dy_ld, size_t npix, int channels, float*
         channel_reduce_kernel<ODAMD_DTYPE_BF16, 2><<<nblk, vecs * rows, lds, st>>>((const char*)dy, dy_ld, nullptr, 0, npix, channels, vecs, rows, nullptr, nullptr, nullptr, nullptr, part);
     else
         return ODAMD_E_ARG;
-    bias_grad_finalize_kernel<<<(channels + 3) / 4, 256, 0, st>>>(part, nblk, channels, dbias);
+    bias_grad_finalize_kernel<<<(channels + 3) / 4, 256, 0, st>>>(part, nblk, channels, vecs * per, dbias);
     return (int)hipGetLastError();
 }
 

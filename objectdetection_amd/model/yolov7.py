@@ -17,6 +17,8 @@ class yolov7(torch.nn.Module):
     def __init__(self, args, config=None):
         super().__init__()
         d, n = _BASE[args.model_type], _DEPTH[args.model_type]
+        self.model_type = args.model_type
+        self.pruned_config = None if config is None else [int(c) for c in config]
         self.output_size = args.output_size
         self.output_class = args.output_class
         self.decode = decode(args)
@@ -222,6 +224,41 @@ class yolov7(torch.nn.Module):
     def forward_deploy(self, x):
         """forward + sigmoid on channels 4: (what `deploy(model)(x)` returns)."""
         return self._decoded(x, True)
+
+    # ---- checkpoints -------------------------------------------------------------------------
+    def checkpoint_meta(self):
+        """Everything needed to rebuild this module from a state_dict: plain Python data only, so the
+        checkpoint can be read with torch.load(..., weights_only=True) (no code runs on load)."""
+        n_cbs = [m.conv.out_channels for m in self.modules() if isinstance(m, cbs)]
+        depth = len(self.elan4.sequential2)
+        config = getattr(self, 'pruned_config', None)
+        if config is None:
+            # a module restored from a reference pickle does not say how it was built: the widths do (the
+            # pruned constructor takes the width of every cbs in module order, train_class.py:367-386)
+            d = _BASE[{1: 's', 2: 'm', 3: 'l'}[depth]]
+            if n_cbs[:4] != [d, 2 * d, 2 * d, 4 * d] or any(w % d for w in n_cbs):
+                config = n_cbs
+        return {'model_type': getattr(self, 'model_type', {1: 's', 2: 'm', 3: 'l'}[depth]),
+                'input_size': int(self.decode.input_size), 'output_class': int(self.output_class),
+                'output_size': tuple(int(v) for v in self.output_size),
+                'output_layer': tuple(int(v) for v in self.decode.output_layer),
+                'anchor_px': self.decode.anchor.tolist(),
+                'config': config, 'cbs_widths': n_cbs}
+
+    @classmethod
+    def from_checkpoint(cls, ckpt):
+        """Inverse of {'state_dict': model.state_dict(), 'meta': model.checkpoint_meta()}."""
+        import argparse
+        meta = ckpt['meta']
+        anchor_px = torch.tensor(meta['anchor_px'], dtype=torch.float32)
+        args = argparse.Namespace(model_type=meta['model_type'], input_size=meta['input_size'],
+                                  output_class=meta['output_class'], output_size=tuple(meta['output_size']),
+                                  output_layer=tuple(meta['output_layer']),
+                                  anchor=(anchor_px / meta['input_size']).tolist())
+        net = cls(args, config=meta['config'])
+        net.decode.anchor = anchor_px          # the exact pixel values, not input_size * (anchor / input_size)
+        net.load_state_dict(ckpt['state_dict'])
+        return net
 
     def __getstate__(self):
         state = self.__dict__.copy()

@@ -26,6 +26,34 @@ parser.add_argument('--iou_threshold', default=0.5, type=float)
 args, _ = parser.parse_known_args()
 
 
+def load_model(model_path):
+    """Checkpoint -> yolov7 module of this build.  Two forms are accepted:
+      * {'state_dict': ..., 'meta': ...} (what train_class writes next to every checkpoint as *.weights.pt):
+        tensors and plain Python data only, read with weights_only=True, nothing in the file is executed;
+      * the reference's own format (train_class.py:262-276, read like predict.py:29): a pickled dict whose
+        'model' entry is the module object.  Its class paths model.yolov7.yolov7 / model.layer.* resolve to
+        this build's classes through the top-level `model` package; unpickling runs code from the file, so
+        only load checkpoints you trust.
+    Anything that does not come out as this build's yolov7 is refused: nothing here runs a network through
+    torch's own operators."""
+    from .model.yolov7 import yolov7
+    ckpt = None
+    try:
+        ckpt = torch.load(model_path, map_location='cpu', weights_only=True)
+    except Exception:                                    # a pickled module: not loadable without running code
+        ckpt = None
+    if isinstance(ckpt, dict) and 'state_dict' in ckpt and 'meta' in ckpt:
+        return yolov7.from_checkpoint(ckpt)
+    ckpt = torch.load(model_path, map_location='cpu', weights_only=False)
+    model = ckpt['model'] if isinstance(ckpt, dict) else ckpt
+    model = getattr(model, 'module', model)
+    if not isinstance(model, yolov7):
+        raise TypeError(f'{model_path}: holds a {type(model).__module__}.{type(model).__name__}, not the yolov7 of '
+                        'objectdetection_amd (put this repository ahead of the reference tree on sys.path so that '
+                        'model.yolov7 resolves to it); there is no fallback through torch operators')
+    return model
+
+
 class predict_class:
     def __init__(self, model_path, args=args, model=None):
         """`model_path`: checkpoint written by training (a dict holding the module under 'model').
@@ -38,7 +66,9 @@ class predict_class:
         self.confidence_threshold = args.confidence_threshold
         self.iou_threshold = args.iou_threshold
         if model is None:
-            model = torch.load(model_path, map_location='cpu', weights_only=False)['model']
+            model = load_model(model_path)
+        if not hasattr(model, 'head_tensors'):
+            raise TypeError('predict_class needs the yolov7 module of objectdetection_amd (no fallback through torch operators)')
         self.model = deploy(model).eval().to(args.device)
         # the reference runs fp16 on a GPU (predict.py:18,31); the MI355X build computes in bf16
         # on the matrix cores instead (float32 parameters stay the master copy)
@@ -81,14 +111,10 @@ class predict_class:
         scale = torch.tensor([[image.shape[1] / self.input_size, image.shape[0] / self.input_size]],
                              dtype=torch.float32, device=self.device)
         with torch.no_grad():
-            if hasattr(self.model.model, 'head_tensors'):
-                heads = self._forward_heads(tensor)
-                dec = self.model.model.decode
-                res = _post.postprocess_heads([h[:1] for h in heads], dec.input_size, dec.anchor,
-                                              self.confidence_threshold, self.iou_threshold, scale)
-            else:
-                res = _post.postprocess(self.model(tensor)[:1].float(), self.confidence_threshold, self.iou_threshold,
-                                        scale)
+            heads = self._forward_heads(tensor)
+            dec = self.model.model.decode
+            res = _post.postprocess_heads([h[:1] for h in heads], dec.input_size, dec.anchor,
+                                          self.confidence_threshold, self.iou_threshold, scale)
         return res.per_image()[0][0]
 
     def predict_batch(self, tensor, shapes=None):

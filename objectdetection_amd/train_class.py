@@ -320,15 +320,24 @@ class train_class:
             import torch.distributed as dist
             st = self.model.train_state()
             # every rank starts from rank 0's parameters and buffers (DDP constructor broadcast)
-            dist.broadcast(st.param, 0)
-            dist.broadcast(st.buffers, 0)
+            te.broadcast_from_rank0(st.param)
+            te.broadcast_from_rank0(st.buffers)
             self.reducer = te.GradReducer(st.grad, n_buckets=3)
             self.optimizer.grad_scale = 1.0 / self.reducer.world
 
     def model_load(self):
         args = self.args
         if os.path.exists(getattr(args, 'weight_path', '')):
-            model_dict = torch.load(args.weight_path, map_location='cpu', weights_only=False)
+            from .predict import load_model
+            model = load_model(args.weight_path)           # weights-only form, or the reference's pickled module
+            try:
+                model_dict = torch.load(args.weight_path, map_location='cpu', weights_only=True)
+                model_dict = {k: v for k, v in model_dict.items() if k not in ('state_dict', 'meta')}
+            except Exception:
+                model_dict = torch.load(args.weight_path, map_location='cpu', weights_only=False)
+            model_dict['model'] = model
+            for k, v in (('epoch_finished', 0), ('optimizer_state_dict', None), ('ema_update', 0), ('standard', 0)):
+                model_dict.setdefault(k, v)
             for p in model_dict['model'].parameters():
                 p.requires_grad_(True)
             if args.weight_again:
@@ -389,6 +398,12 @@ class train_class:
         image_batch = image_batch.to(args.device, non_blocking=True)
         plan = model.train_plan(image_batch.shape[0], image_batch.shape[2])
         plan.reducer = self.reducer
+        if self.reducer is not None and getattr(args, 'broadcast_buffers', True):
+            # DistributedDataParallel's default broadcast_buffers=True (train_class.py:38-40 does not override it):
+            # before every forward the BatchNorm running statistics and counters of rank 0 replace everyone's
+            st = model.train_state()
+            te.broadcast_from_rank0(st.buffers)
+            te.broadcast_from_rank0(st.counters)
         pred = model(image_batch)
         losses = self.loss(pred, screen_list, label_expend)
         self.optimizer.zero_grad()
@@ -452,6 +467,18 @@ class train_class:
         self.model.train()
         return val_loss, precision, recall, m_ap
 
+    @staticmethod
+    def save_checkpoint(model_dict, path):
+        """Writes `path` in the reference's format (train_class.py:262-276: the dict with the pickled module)
+        and, next to it, `<path minus extension>.weights.pt`: the same dict with the module replaced by its
+        state_dict + rebuild data, loadable with torch.load(weights_only=True)."""
+        torch.save(model_dict, path)
+        model = model_dict['model']
+        light = {k: v for k, v in model_dict.items() if k not in ('model', 'optimizer_state_dict')}
+        light['state_dict'] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        light['meta'] = model.checkpoint_meta()
+        torch.save(light, os.path.splitext(path)[0] + '.weights.pt')
+
     def train(self):
         args = self.args
         history = []
@@ -487,9 +514,9 @@ class train_class:
                     out['model'] = self.ema.ema_model if self.ema else self.model
                     out['optimizer_state_dict'] = self.optimizer.state_dict()
                     if save and (epoch % getattr(args, 'save_epoch', 5) == 0 or epoch == args.epoch):
-                        torch.save(out, save)
+                        self.save_checkpoint(out, save)
                     if best and is_best:
-                        torch.save(out, best)
+                        self.save_checkpoint(out, best)
             if args.distributed:
                 torch.distributed.barrier()
         return history

@@ -97,6 +97,28 @@ class FlatState:
         return self.grad.data_ptr() + 4 * self.offsets[id(p)]
 
 
+def _gloo_with_gpu_tensor(t, group=None):
+    import torch.distributed as dist
+    return dist.is_initialized() and dist.get_backend(group) == 'gloo' and t.is_cuda
+
+
+def broadcast_from_rank0(t, group=None):
+    """DDP's constructor broadcast (train_class.py:38-40).  RCCL takes device tensors; gloo (CPU tests and the
+    one-GPU rehearsal of the multi-rank path) is only ever given host tensors: its own staging of device
+    tensors runs on internal streams and a helper thread, and a later blocking host-to-device copy of the
+    same process (legacy default-stream semantics: it waits for every stream of the process) was seen to wait
+    on that machinery forever when two ranks share one GPU."""
+    import torch.distributed as dist
+    if _gloo_with_gpu_tensor(t, group):
+        torch.cuda.current_stream().synchronize()
+        host = t.cpu()
+        dist.broadcast(host, 0, group=group)
+        t.copy_(host)
+        torch.cuda.current_stream().synchronize()
+        return
+    dist.broadcast(t, 0, group=group)
+
+
 class GradReducer:
     """Bucketed data-parallel gradient all-reduce over torch.distributed (RCCL on GPUs, gloo in the
     CPU tests).  The flat gradient buffer is cut into contiguous buckets; bucket i is started as
@@ -113,7 +135,7 @@ class GradReducer:
         self.bounds = [(i * per, min(n, (i + 1) * per)) for i in range(n_buckets) if i * per < n]
         self.handles = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.host_staged = dist.is_initialized() and dist.get_backend(group) == 'gloo' and flat_grad.is_cuda
+        self.host_staged = _gloo_with_gpu_tensor(flat_grad, group)
 
     def bucket_of(self, offset):
         for i, (a, b) in enumerate(self.bounds):
@@ -121,13 +143,17 @@ class GradReducer:
                 return i
         return len(self.bounds) - 1
 
+    def buckets_of(self, offset, numel):
+        """Every bucket that holds a part of [offset, offset + numel): bucket bounds are multiples of 1024
+        elements and cut through tensors, so a tensor can live in two (or more) buckets."""
+        return [i for i, (a, b) in enumerate(self.bounds) if a < offset + max(numel, 1) and offset < b]
+
     def ready(self, i):
         if self.world > 1:
             a, b = self.bounds[i]
             if self.host_staged:
-                # gloo (rehearsals on one GPU only) stages CUDA tensors through the host itself and was seen to
-                # stall now and then with several asynchronous buckets in flight: do the staging here and
-                # reduce host tensors synchronously.  RCCL (the production backend) is stream ordered.
+                # gloo is only ever given host tensors (see broadcast_from_rank0); RCCL, the production
+                # backend, reduces the device buffer in place, asynchronously and stream ordered
                 torch.cuda.current_stream().synchronize()
                 host = self.flat[a:b].cpu()
                 self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -271,9 +297,8 @@ class TrainPlan:
                                      [None, wf.data_ptr(), None, None, raw.data_ptr(), B, ho, wo, cout, cphys, 0,
                                       self.dtype], 'first', 0))
                 else:
-                    x = op['x']
-                    assert x.cphys == x.c, 'training needs gap-free channel slices (widths that are multiples of 16)'
-                    wf = torch.empty(cout * k * k * x.cphys, dtype=self.tdt, device=dev)
+                    x = op['x']        # may hold zero-padded gaps (pruned, irregular widths): the packed weights
+                    wf = torch.zeros(cout * k * k * x.cphys, dtype=self.tdt, device=dev)   # have zero columns there
                     wb = torch.zeros(x.cphys * k * k * cphys, dtype=self.tdt, device=dev)
                     pack.append(self._pack_desc(m.conv.weight, wf, wb, x, cout))
                     op['wf'], op['wb'] = wf, wb
@@ -285,7 +310,7 @@ class TrainPlan:
                 m, x = op['mod'], op['x']
                 cout = m.output.out_channels
                 cphys = _round_up(cout, self.pb.align)
-                wf = torch.empty(cout * x.cphys, dtype=self.tdt, device=dev)
+                wf = torch.zeros(cout * x.cphys, dtype=self.tdt, device=dev)     # gap columns stay zero
                 wb = torch.zeros(x.cphys * cphys, dtype=self.tdt, device=dev)
                 pack.append(self._pack_desc(m.output.weight, wf, wb, x, cout))
                 out = torch.empty((B, cout, x.h, x.w), dtype=torch.float32, device=dev)
@@ -382,9 +407,20 @@ class TrainPlan:
                                  self.size, self.size, 3, cout, 3, 1, self.dtype], 'wgrad', None))
                 else:
                     x = op['x']
-                    bwd.append((lib.odamd_conv_wgrad,
-                                [self._aptr(x), self._ld(x), raw.data_ptr(), cphys, st.grad_ptr(m.conv.weight), B, x.h,
-                                 x.w, x.c, cout, k, op['s'], self.dtype], 'wgrad', None))
+                    if len(x.segments) == 1:
+                        bwd.append((lib.odamd_conv_wgrad,
+                                    [self._aptr(x), self._ld(x), raw.data_ptr(), cphys, st.grad_ptr(m.conv.weight), B, x.h,
+                                     x.w, x.c, cout, k, op['s'], self.dtype], 'wgrad', None))
+                    else:
+                        # a concat of irregular widths: every slice is a run of real channels followed by zero
+                        # padding, the weight's input channels are the runs back to back.  One weight-gradient
+                        # launch per run into a scratch tensor, added to its columns of the parameter gradient.
+                        src = 0
+                        for off, n in x.segments:
+                            bwd.append((lib.odamd_conv_wgrad,
+                                        [self._aptr(x) + off * self.es, self._ld(x), raw.data_ptr(), cphys, None, B, x.h,
+                                         x.w, n, cout, k, op['s'], self.dtype], 'wgrad', ('columns', m.conv.weight, src, n)))
+                            src += n
                     d = self._conv_desc(raw.data_ptr(), op['wb'], None, self._gptr(x), raw.shape[1], raw.shape[2], cphys,
                                         x.cphys, cphys, self._ld(x), k, 1, upz=int(op['s'] == 2), accum=1)
                     bwd.append((lib.odamd_conv_forward, [C.byref(d)], 'dgrad', None))
@@ -541,6 +577,16 @@ class TrainPlan:
                 if pending is not None:
                     for bucket in pending.pop(i, ()):
                         reducer.ready(bucket)
+            elif name == 'wgrad' and extra is not None:
+                _, weight, src, n = extra
+                cout, _, k, _ = weight.shape
+                tmp = self.bias_tmp.get(('wseg', cout, n, k))
+                if tmp is None:
+                    tmp = self.bias_tmp[('wseg', cout, n, k)] = torch.zeros((cout, n, k, k), dtype=torch.float32, device=self.dev)
+                tmp.zero_()
+                args[4] = tmp.data_ptr()
+                check(fn(*args, stream), name)
+                weight.grad[:, src:src + n].add_(tmp)
             elif name == 'bias_grad':
                 _, bias, cout, cphys = extra
                 tmp = self.bias_tmp.get(id(bias))
@@ -559,8 +605,10 @@ class TrainPlan:
         last = {}
         for i, (fn, args, name, _) in enumerate(self.bwd):
             if fn == 'mark':
+                # a bucket is final once the LAST tensor with any element inside it has its gradient
                 for p in args:
-                    last[reducer.bucket_of(st.offsets[id(p)])] = i
+                    for b in reducer.buckets_of(st.offsets[id(p)], p.numel()):
+                        last[b] = i
         plan = {}
         for bucket, i in last.items():
             plan.setdefault(i, []).append(bucket)

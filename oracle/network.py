@@ -20,9 +20,11 @@ class Net:
     sd        : dict name -> tensor (parameters may require grad)
     training  : BN uses batch statistics and updates running buffers in `sd`
     taps      : optional dict filled with named intermediate activations
-    act_bf16  : round every cbs output to bf16 (straight-through gradient): emulates the storage
-                precision of the bf16 compute path, so that max-pool arg-max decisions are taken on the
-                values that path actually pools (float32 activations decide near-ties differently)
+    act_bf16  : emulate the storage precision of the bf16 compute path: convolution weights, the raw
+                convolution output and every cbs output are rounded to bf16 (straight-through gradient),
+                all arithmetic stays in the tensors' own (float32 / float64) precision.  Max-pool arg-max
+                decisions are then taken on the values that path actually pools, and batch-statistics
+                BatchNorm sees the rounded raw tensor, as the kernels do.
     """
 
     def __init__(self, sd, training=False, taps=None, act_bf16=False):
@@ -43,9 +45,9 @@ class Net:
 
     # ---- model/layer.py:4-16 -------------------------------------------------------
     def cbs(self, p, x, stride=1):
-        w = self.sd[p + '.conv.weight']
+        w = self._q(self.sd[p + '.conv.weight'])
         k = w.shape[-1]
-        y = F.conv2d(x, w, None, stride=stride, padding=(k - 1) // 2)
+        y = self._q(F.conv2d(x, w, None, stride=stride, padding=(k - 1) // 2))
         y = F.batch_norm(y, self.sd[p + '.bn.running_mean'], self.sd[p + '.bn.running_var'],
                          self.sd[p + '.bn.weight'], self.sd[p + '.bn.bias'],
                          self.training, BN_MOMENTUM, BN_EPS)
@@ -91,7 +93,7 @@ class Net:
 
     # ---- model/layer.py:234-236 ----------------------------------------------------
     def head(self, p, x, n_anchor, k):
-        y = F.conv2d(x, self.sd[p + '.output.weight'], self.sd[p + '.output.bias'])
+        y = F.conv2d(x, self._q(self.sd[p + '.output.weight']), self.sd[p + '.output.bias'])
         b, _, h, w = y.shape
         return y.reshape(b, n_anchor, h, w, k)   # raw reshape, no permute
 

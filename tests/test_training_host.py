@@ -91,3 +91,49 @@ def test_bucketed_all_reduce_two_ranks_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert out[0] and out[1]
+
+
+def test_bucket_plan_waits_for_every_tensor_inside_a_bucket():
+    """Bucket bounds cut through tensors.  A bucket may only be reduced after the LAST tensor with any element
+    in it has its gradient; a tensor that straddles a bound (here a bias forced across it) belongs to both."""
+    from objectdetection_amd.train_engine import GradReducer, TrainPlan
+
+    class _Red(GradReducer):
+        def __init__(self, bounds):
+            self.bounds = bounds
+
+    red = _Red([(0, 100), (100, 200), (200, 300)])
+    assert red.buckets_of(0, 100) == [0]
+    assert red.buckets_of(96, 8) == [0, 1]            # straddles the first bound
+    assert red.buckets_of(100, 100) == [1]
+    assert red.buckets_of(50, 200) == [0, 1, 2]
+    assert red.buckets_of(299, 1) == [2]
+
+    class _P:
+        def __init__(self, n):
+            self._n = n
+
+        def numel(self):
+            return self._n
+
+    # backward order: tensor c (bucket 2) first, then the straddling bias b, then a
+    a, b, c = _P(96), _P(8), _P(196)
+    offsets = {id(a): 0, id(b): 96, id(c): 104}
+
+    class _State:
+        pass
+
+    class _Plan:
+        _bucket_plan = TrainPlan._bucket_plan
+
+    plan = _Plan()
+    plan.state = _State()
+    plan.state.offsets = offsets
+    plan.bwd = [('mark', (c,), 'mark', None), ('mark', (b,), 'mark', None), ('mark', (a,), 'mark', None)]
+    got = plan._bucket_plan(red)
+    # bucket 2 is final after c (launch 0) ... bucket 1 holds the tail of b as well -> only after launch 1
+    assert got == {0: [2], 1: [1], 2: [0]}
+    # with the bias marked BEFORE the tensor that fills the rest of its bucket, the bucket waits for that tensor
+    plan.bwd = [('mark', (b,), 'mark', None), ('mark', (c,), 'mark', None), ('mark', (a,), 'mark', None)]
+    got = plan._bucket_plan(red)
+    assert got == {1: [1, 2], 2: [0]}
