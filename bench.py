@@ -42,6 +42,7 @@ def parse():
     p.add_argument('--train-classes', type=int, default=5)
     p.add_argument('--train-steps', type=int, default=None, help='default: --steps')
     p.add_argument('--no-train', action='store_true', help='skip the training leg')
+    p.add_argument('--no-extra', action='store_true', help='skip the end-to-end and dense-candidate legs')
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                    help='process-group backend (gloo + --share-gpu rehearses the multi-rank path on a one-GPU box)')
     p.add_argument('--share-gpu', action='store_true', help='every rank uses cuda:0 (rehearsal only)')
@@ -50,26 +51,116 @@ def parse():
 
 
 def cpu_baseline(model, a, margs, x_cpu):
-    """The CPU restatement of the same path (oracle), bounded sample, timed on this host."""
-    from oracle import network, postprocess as opost
+    """The CPU restatement of the same path (oracle), bounded sample, timed on this host.  Also the
+    batch-1 CPU configuration split by stage (forward / box decode / filter + NMS), for C = 80 and C = 1."""
+    from oracle import network, patterns, postprocess as opost
+    from objectdetection_amd.model.yolov7 import yolov7
     cores = os.cpu_count() or 1
     torch.set_num_threads(min(cores, 64))
     used = torch.get_num_threads()
+
+    def stages(sd, args_c, x1):
+        net = network.Net(sd)
+        with torch.no_grad():
+            net.trunk(x1, args_c.output_class, args_c.output_layer[0])                      # warm-up
+            t0 = time.perf_counter()
+            heads = net.trunk(x1, args_c.output_class, args_c.output_layer[0])
+            t1 = time.perf_counter()
+            pred = network.deploy_sigmoid(network.decode(heads, args_c.input_size, args_c.anchor)).numpy()
+            t2 = time.perf_counter()
+        rows, kept = opost.predict_decode(pred[0], (a.size, a.size, 3), a.size, a.conf, a.iou)
+        t3 = time.perf_counter()
+        cand = len(opost.filter_indices(pred[0], a.conf)[1])
+        return {'forward_us': (t1 - t0) * 1e6, 'decode_us': (t2 - t1) * 1e6, 'filter_nms_us': (t3 - t2) * 1e6,
+                'candidates': cand, 'kept': len(kept)}
+
     sd = {k: v.detach().cpu().float().clone() for k, v in model.state_dict().items()}
-    n_fwd = 2
-    with torch.no_grad():
-        network.yolov7_forward(sd, x_cpu[:1], margs, deploy=True)          # warm-up
-        t0 = time.perf_counter()
-        pred = network.yolov7_forward(sd, x_cpu[:n_fwd], margs, deploy=True).numpy()
-        t_fwd = (time.perf_counter() - t0) / n_fwd
+    c80 = stages(sd, margs, x_cpu[:1])
+    args1 = patterns.default_args(input_size=a.size, output_class=1)
+    torch.manual_seed(999)
+    sd1 = {k: v.detach().float().clone() for k, v in yolov7(args1).state_dict().items()}
+    c1 = stages(sd1, args1, x_cpu[:1])
+    t_img = (c80['forward_us'] + c80['decode_us'] + c80['filter_nms_us']) * 1e-6
+    return {'value': 1.0 / t_img, 'unit': 'images/sec', 'cores': used, 'kind': 'port',
+            'sample': f'1 image, batch 1, float32: forward on {used} torch threads + numpy decode/NMS on 1 core '
+                      '(the restated loop indexes boxes; the reference loop, predict.py:86-90, copies whole rows per '
+                      'iteration and is several times slower)',
+            'forward_ms_per_image': c80['forward_us'] * 1e-3,
+            'postprocess_s_per_image': (c80['decode_us'] + c80['filter_nms_us']) * 1e-6,
+            'batch1_cpu_by_stage_us': {'C80': c80, 'C1': c1}}
+
+
+def end_to_end_leg(model, a, margs, pipe, x_cpu, steps=6):
+    """The same step fed from the HOST and read back to the host: page-locked uint8 HWC images -> H2D ->
+    / 255 and HWC -> CHW on the device -> network -> decode / NMS -> kept rows of every image on the host
+    (what predict.py:53-58 hands back).  Reported beside `value`, never as `value`."""
+    import ctypes as C
+    from objectdetection_amd._lib import lib, check
+    dev = next(model.parameters()).device
+    img8 = (x_cpu.permute(0, 2, 3, 1) * 255).to(torch.uint8).contiguous().pin_memory()
+    x = torch.empty((a.batch, 3, a.size, a.size), dtype=torch.float32, device=dev)
+
+    def step():
+        d8 = img8.to(dev, non_blocking=True)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for b in range(a.batch):
+            check(lib.odamd_preprocess_u8(d8[b].data_ptr(), a.size, a.size, x[b].data_ptr(), a.size, st), 'preprocess_u8')
+        res = pipe.submit(x)
+        return res, d8
+
+    pending = None
+    for i in range(2):
+        r, keep = step()
+        pipe.synchronize()
+        r.per_image()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rows, kept = opost.predict_decode(pred[0], (a.size, a.size, 3), a.size, a.conf, a.iou)
-    t_post = time.perf_counter() - t0
-    return {'value': 1.0 / (t_fwd + t_post), 'unit': 'images/sec', 'cores': used, 'kind': 'port',
-            'sample': f'{n_fwd} images forward on {used} torch threads ({t_fwd * 1e3:.0f} ms/img) + numpy '
-                      f'decode/NMS of 1 image on 1 core ({t_post:.2f} s, {len(kept)} kept); reference loop is '
-                      'single-threaded Python (predict.py:86-90)',
-            'forward_ms_per_image': t_fwd * 1e3, 'postprocess_s_per_image': t_post}
+    rows_out = 0
+    for i in range(steps):
+        cur = step()
+        if pending is not None:                 # read batch i-1 back while batch i runs
+            for e in (pending[0].done if isinstance(pending[0].done, list) else [pending[0].done]):
+                e.synchronize()
+            rows_out += sum(0 if r is None else len(r) for r, _ in pending[0].per_image())
+        pending = cur
+    pipe.synchronize()
+    rows_out += sum(0 if r is None else len(r) for r, _ in pending[0].per_image())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'images_per_sec': a.batch * steps / dt, 'ms_per_step': dt / steps * 1e3, 'steps': steps,
+            'h2d_bytes_per_step': int(img8.numel()), 'kept_rows_per_step': rows_out / steps,
+            'note': 'uint8 HWC host images in, kept rows on the host out; H2D + device-side /255 and transpose + D2H inside the timed region'}
+
+
+def dense_leg(a, dev, steps=3):
+    """Dense-candidate configuration: 1280 x 1280, batch 16, 80 classes, confidence 0.001 (random init: nearly
+    every one of the 100 800 rows per image is a candidate)."""
+    from objectdetection_amd import postprocess
+    from objectdetection_amd.model.yolov7 import yolov7
+    from oracle import patterns
+    size, batch = 1280, 16
+    margs = patterns.default_args(input_size=size, output_class=80)
+    torch.manual_seed(999)
+    model = yolov7(margs).to(dev).eval()
+    x = torch.rand(batch, 3, size, size, generator=torch.Generator().manual_seed(999)).to(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    net_ms, post_ms = [], []
+    for i in range(steps + 1):
+        ev[0].record()
+        heads = model.head_tensors(x)
+        ev[1].record()
+        res = postprocess.postprocess_heads(heads, size, margs.anchor, 0.001, 0.5)
+        ev[2].record()
+        torch.cuda.synchronize()
+        if i:
+            net_ms.append(ev[0].elapsed_time(ev[1]))
+            post_ms.append(ev[1].elapsed_time(ev[2]))
+    cand, kept = res.cand.float().mean().item(), res.count.float().mean().item()
+    n, p = sorted(net_ms)[len(net_ms) // 2], sorted(post_ms)[len(post_ms) // 2]
+    del model, x, heads, res
+    return {'workload': 'YOLOv7-s 1280x1280 batch 16 bf16, C=80, conf 0.001, iou 0.5', 'network_ms_per_batch': n,
+            'postprocess_ms_per_batch': p, 'ms_per_batch': n + p, 'images_per_sec': batch / ((n + p) * 1e-3),
+            'decode_nms_us_per_image': p * 1e3 / batch, 'candidates_per_image': cand, 'kept_per_image': kept}
 
 
 def train_leg(a, dev, rank, world, dist, steps, warmup, amp=False):
@@ -256,8 +347,12 @@ def main():
         # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); null when the file is absent
         traffic = None
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')) as fh:
-                traffic = json.load(fh)['families'][dom_name]['traffic_bytes_per_launch']
+            for name in ('r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
+                path = os.path.join(ROOT, 'profiles', name)
+                if os.path.exists(path):
+                    with open(path) as fh:
+                        traffic = json.load(fh)['families'][dom_name]['traffic_bytes_per_launch']
+                    break
         except (OSError, KeyError, ValueError):
             pass
         roof.update({'frac': roof['achieved'] / roof['peak'], 'traffic': traffic, 'kernel': dom_name,
@@ -281,6 +376,11 @@ def main():
             'candidates_per_image': float(cand.float().mean()), 'kept_per_image': float(cnt.float().mean()),
             'kernel_families_ms': {k: round(v['ms'], 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])},
         }
+        if world == 1 and not a.no_extra:
+            out['end_to_end'] = end_to_end_leg(model, a, margs, pipe, x_cpu)
+            torch.cuda.empty_cache()
+            out['dense'] = dense_leg(a, dev)
+            torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(model, a, margs, x_cpu)
 

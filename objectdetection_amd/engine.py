@@ -467,7 +467,10 @@ def compute_dtype_for(module):
     return F32
 
 
-_plans = {}
+def module_plans(module):
+    """Per-module plan cache, kept ON the module (a reference cycle the collector can free, where a global
+    table keyed by id(module) kept every module and all its plan buffers alive for the life of the process)."""
+    return module.__dict__.setdefault('_odamd_plans', {})
 
 
 def run_module(module, x, emit=None):
@@ -477,8 +480,9 @@ def run_module(module, x, emit=None):
     if module.training:
         return _run_module_train(module, x, emit)
     dtype = compute_dtype_for(module)
-    key = (id(module), tuple(x.shape), dtype, x.device.index)
-    plan = _plans.get(key)
+    plans = module_plans(module)
+    key = (tuple(x.shape), dtype, x.device.index)
+    plan = plans.get(key)
     if plan is None:
         b, c, h, w = x.shape
         pb = PlanBuilder(b, dtype, x.device)
@@ -486,7 +490,7 @@ def run_module(module, x, emit=None):
         out = (emit or module._emit)(pb, xin)
         pb.to_nchw(out)
         plan = Plan(pb)
-        _plans[key] = plan
+        plans[key] = plan
     y = plan.run(x.detach().float().contiguous())
     return y.clone() if x.dtype == torch.float32 else y.to(x.dtype)
 

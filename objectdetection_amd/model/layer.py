@@ -34,6 +34,13 @@ class _Block(torch.nn.Module):
     def forward(self, x):
         return engine.run_module(self, x)
 
+    def __getstate__(self):
+        """Pickling (checkpoints pickle whole modules): execution plans and their buffers stay behind."""
+        state = self.__dict__.copy()
+        for k in ('_odamd_plans', '_odamd_train_plans', '_odamd_hook'):
+            state.pop(k, None)
+        return state
+
 
 class cbs(_Block):
     """Conv2d(no bias, 'same' padding) -> BatchNorm2d(eps 1e-3, momentum 0.03) -> SiLU."""
@@ -201,15 +208,16 @@ class head(_Block):  # in_ -> (batch, layer, output_size, output_size, 5 + outpu
         if not x.is_cuda:
             raise RuntimeError('objectdetection_amd blocks run on the GPU only (no CPU fallback)')
         dtype = engine.compute_dtype_for(self)
-        key = (id(self), tuple(x.shape), dtype, x.device.index)
-        plan = engine._plans.get(key)
+        plans = engine.module_plans(self)
+        key = (tuple(x.shape), dtype, x.device.index)
+        plan = plans.get(key)
         if plan is None:
             b, c, h, w = x.shape
             pb = engine.PlanBuilder(b, dtype, x.device)
             op = pb.head(self, pb.from_nchw(c, h, w))
             plan = engine.Plan(pb)
             plan.head_op = op
-            engine._plans[key] = plan
+            plans[key] = plan
         plan.run(x.detach().float().contiguous())
         y = plan.head_op['out']
         # raw reinterpretation of the NCHW result, exactly as the reference reshapes it

@@ -6,6 +6,7 @@ and name the current HIP stream.
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -76,14 +77,18 @@ class PostResult:
         self.rows, self.idx, self.count, self.cand = rows, idx, count, cand
 
     def per_image(self):
-        """Host copy: list of (rows ndarray (kept,K) or None, kept row indices ndarray)."""
-        cnt = self.count.cpu().tolist()
-        rows = self.rows.cpu().numpy()
-        idx = self.idx.cpu().numpy()
-        out = []
-        for b, n in enumerate(cnt):
-            n = min(n, idx.shape[1])
-            out.append((rows[b, :n].copy() if n else None, idx[b, :n].astype('int64')))
+        """Host copy: list of (rows ndarray (kept,K) or None, kept row indices ndarray).  Only the kept rows
+        cross to the host (the device buffers are sized for the worst case: every row kept)."""
+        cnt = [min(n, self.idx.shape[1]) for n in self.count.cpu().tolist()]
+        if sum(cnt) == 0:
+            return [(None, np.zeros((0,), np.int64)) for _ in cnt]
+        # two device-side gathers and two copies for the whole batch
+        rows = torch.cat([self.rows[b, :n] for b, n in enumerate(cnt)]).cpu().numpy()
+        idx = torch.cat([self.idx[b, :n] for b, n in enumerate(cnt)]).cpu().numpy().astype('int64')
+        out, o = [], 0
+        for n in cnt:
+            out.append((rows[o:o + n] if n else None, idx[o:o + n]))
+            o += n
         return out
 
 

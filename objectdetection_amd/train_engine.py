@@ -407,7 +407,7 @@ class TrainPlan:
                                  self.size, self.size, 3, cout, 3, 1, self.dtype], 'wgrad', None))
                 else:
                     x = op['x']
-                    if len(x.segments) == 1:
+                    if x.cphys == x.c:      # no padding gaps: the whole concat is one run of real channels
                         bwd.append((lib.odamd_conv_wgrad,
                                     [self._aptr(x), self._ld(x), raw.data_ptr(), cphys, st.grad_ptr(m.conv.weight), B, x.h,
                                      x.w, x.c, cout, k, op['s'], self.dtype], 'wgrad', None))
