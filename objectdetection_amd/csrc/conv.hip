@@ -14,6 +14,8 @@
 // workgroup.  LDS rows are padded by 16 bytes so the 16-byte fragment reads are conflict free.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 #include "odamd.h"
@@ -457,22 +459,36 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
     // lane (r, h) holds, for pixel (group i, r), channels {8g + 4h + e : g, e in 0..3} of group j.
     const int cw0 = co0 + wc * CGW * 32;     // first channel of this wave
     if (p.nchw) {   // float32 NCHW: lanes are consecutive pixels, stores coalesce as they are
+        // The affine constants of the block's channels go through LDS (free after the main loop): every lane
+        // needs 16 * CGW of them, and loading them from global memory between the stores serialises the epilogue
+        // into one memory round trip per channel.
+        float* tab = (float*)lds;
+        for (int t = tid; t < 32 * CG; t += 256) {
+            const int c = min(co0 + t, p.Cout - 1);
+            tab[t] = p.scale ? p.scale[c] : 1.0f;
+            tab[32 * CG + t] = p.shift ? p.shift[c] : 0.0f;
+        }
+        __syncthreads();
+        float* yb = (float*)p.y + (size_t)b * p.Cout * p.Ho * p.Wo;
+        const int plane = p.Ho * p.Wo;
 #pragma unroll
         for (int j = 0; j < CGW; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g) {
+                const int cl = (wc * CGW + j) * 32 + 8 * g + 4 * h;
+                const float4 sc4 = *(const float4*)(tab + cl), sh4 = *(const float4*)(tab + 32 * CG + cl);
+                const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int c = cw0 + j * 32 + 8 * g + 4 * h + e;
-                    if (c >= p.Cout) continue;
-                    const float scv = p.scale ? p.scale[c] : 1.0f, shv = p.shift ? p.shift[c] : 0.0f;
+                    const int c = co0 + cl + e;
 #pragma unroll
                     for (int i = 0; i < PGW; ++i) {
-                        float t = acc[i][j][4 * g + e] * scv + shv;
+                        float t = acc[i][j][4 * g + e] * scv[e] + shv[e];
                         if (p.act) t = silu<DT>(t);
-                        if (opix[i] >= 0) ((float*)p.y)[((size_t)b * p.Cout + c) * p.Ho * p.Wo + opix[i]] = t;
+                        if (c < p.Cout && opix[i] >= 0) yb[(size_t)c * plane + opix[i]] = t;
                     }
                 }
+            }
         return;
     }
     // NHWC: transposed through a wave-private LDS slice (see nhwc_epilogue)
@@ -811,7 +827,9 @@ conv_first_kernel(const float* __restrict__ img, const float* __restrict__ w, co
 // 3x3 stride 2).  The 16-channel full-resolution activation between them is the largest tensor of
 // the network (writing and re-reading it is about as much HBM traffic as the image and the second
 // layer's output together); here it only exists as a bf16 patch in LDS.
-// Workgroup (4 waves) = 4 x 32 output pixels of the second layer:
+// Persistent workgroups (4 waves, as many as the device keeps resident) loop over tiles of 4 x 32 output pixels of
+// the second layer; the weights of both layers stay in registers / LDS for the whole launch, and the image patch of
+// the next tile is fetched into registers while the current one is computed.  Per tile:
 //   A. image halo patch (11 x 67 pixels) -> LDS as bf16 (c0, c1, c2, 0) records
 //   B. first layer for the 9 x 65 pixels the second layer reads: three v_mfma_f32_32x32x16_bf16 per 32
 //      pixels (see first_weights_frag), affine + SiLU, bf16 into the LDS patch; pixels
@@ -820,16 +838,25 @@ conv_first_kernel(const float* __restrict__ img, const float* __restrict__ w, co
 //   C. second layer: wave w owns output row w (32 pixels x 32 channels), nine v_mfma_f32_32x32x16_bf16
 //      (one per tap) with the weights held in registers; NHWC epilogue through LDS as everywhere.
 // ------------------------------------------------------------------------------------------
+#ifdef ODAMD_LAB_STAMPS
+#define F2_STAMP(i) do { if (lane == 0 && blockIdx.x < 1024 && ((i) < 2 || j == 13)) g_lab_stamps[(blockIdx.x * 8 + wave) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define F2_STAMP_AT(i, jj) do { if (lane == 0 && blockIdx.x < 1024 && j == (jj)) g_lab_stamps[(blockIdx.x * 8 + wave) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define F2_STAMP_AT(i, jj) do { } while (0)
+#define F2_STAMP(i) do { } while (0)
+#endif
 namespace first2 {
 constexpr int TH = 4, TW = 32;   // TH = waves per workgroup
+constexpr int SEG = 10;          // vertically adjacent tiles a workgroup takes in one go
 constexpr int P1H = 2 * TH + 1, P1W = 2 * TW + 1;      // first-layer pixels needed: 9 x 65
 constexpr int P1EVEN = (P1W + 1) / 2;                   // even columns come first in a patch row
 constexpr int P0H = P1H + 2, P0W = P1W + 2, P0P = P0W + 2;   // image patch 11 x 67 (+2 zero columns)
 constexpr int PS = 48;                                  // bytes per first-layer pixel record (32 + 16 pad)
 constexpr int P1_BYTES = (P1H * P1W * PS + 255) & ~255;
 constexpr int STAGE_BYTES = TH * 32 * (128 + 16);       // epilogue slices of the waves (reuse the patch)
-constexpr int P0_BYTES = P0H * P0P * 8;                 // bf16 (c0, c1, c2, 0) per image pixel
-constexpr int LDS_BYTES = (P1_BYTES > STAGE_BYTES ? P1_BYTES : STAGE_BYTES) + P0_BYTES;
+constexpr int P0_BYTES = (P0H * P0P * 8 + 15) & ~15;    // bf16 (c0, c1, c2, 0) per image pixel
+constexpr int W1_BYTES = 9 * 64 * 16;                   // second-layer weights as MFMA fragments
+constexpr int LDS_BYTES = (P1_BYTES > STAGE_BYTES ? P1_BYTES : STAGE_BYTES) + P0_BYTES + W1_BYTES;
 }
 
 // First layer on the matrix cores from a bf16 (c0,c1,c2,0) image patch in LDS: per kernel row ky the
@@ -854,24 +881,58 @@ __device__ __forceinline__ void first_weights_frag(const float* __restrict__ w0,
     }
 }
 
-__global__ void __launch_bounds__(64 * first2::TH)
+// One tile of the persistent loop: `j` counts this workgroup's tiles; a workgroup takes items (image, column of
+// tiles, run of SEG vertically adjacent tiles) and walks down the run, so the three image rows two vertically
+// adjacent tiles share are read again while still in the L2 of the same XCD.  Items are dealt to the workgroups of
+// one XCD as a contiguous range (workgroup w runs on XCD w % 8), which keeps horizontal neighbours on one L2 as well.
+struct First2Tile { int b, oy0, ox0; bool valid; };
+// First tile (k = 0) of the item this workgroup takes in round i.
+__device__ __forceinline__ First2Tile first2_item(int i, int nitems, int tiles_x, int segs_y) {
+    using namespace first2;
+    const int w = blockIdx.x;
+    const int per_xcd = (nitems + 7) >> 3, slots = gridDim.x >> 3;  // the host launches a multiple of 8 workgroups
+    const int idx = (w >> 3) + i * slots;
+    const int item = (w & 7) * per_xcd + idx;
+    First2Tile t;
+    t.valid = idx < per_xcd && item < nitems;
+    const int it = t.valid ? item : 0;
+    const int tx = it % tiles_x, rest = it / tiles_x, sy = rest % segs_y;
+    t.b = rest / segs_y;
+    t.oy0 = sy * SEG * TH;
+    t.ox0 = tx * TW;
+    return t;
+}
+// Tile k of the item whose first tile is `first` (tiles past the bottom of the image do not exist).
+__device__ __forceinline__ First2Tile first2_step(const First2Tile& first, int k, int tiles_y) {
+    First2Tile t = first;
+    t.oy0 = first.oy0 + k * first2::TH;
+    t.valid = first.valid && t.oy0 < tiles_y * first2::TH;
+    if (!t.valid) t.b = t.oy0 = t.ox0 = 0;
+    return t;
+}
+
+__global__ void __launch_bounds__(64 * first2::TH) __attribute__((amdgpu_waves_per_eu(3, 3)))
 conv_first2_kernel(const float* __restrict__ img, const float* __restrict__ w0, const float* __restrict__ scale0,
                    const float* __restrict__ shift0, const char* __restrict__ w1, const float* __restrict__ scale1,
                    const float* __restrict__ shift1, char* __restrict__ y, int H, int W, int Ho, int Wo, int y_ld,
-                   unsigned ybytes) {
+                   unsigned ybytes, int nitems, int tiles_x, int tiles_y, int segs_y, int rounds) {
     using namespace first2;
     constexpr int DT = ODAMD_DTYPE_BF16;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* p1 = lds;
     char* p0 = lds + (P1_BYTES > STAGE_BYTES ? P1_BYTES : STAGE_BYTES);
-    const int b = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    char* wl = p0 + P0_BYTES;              // second-layer weight fragments
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
+    int j = 0;
+    F2_STAMP(0);
 
-    // second-layer weights [32][3][3][16] bf16: lane (r, h) keeps its 8 input channels of every tap
-    u32x4 a[9];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) a[tap] = *(const u32x4*)(w1 + ((r * 9 + tap) * 16 + 8 * h) * 2);
+    // ---- constants of the whole launch --------------------------------------------------------------
+    // second-layer weights [32][3][3][16] bf16 -> LDS in fragment order [tap][lane (r, h)][8 input channels]
+    for (int t = tid; t < 9 * 64; t += 64 * TH) {
+        const int tap = t >> 6, l = t & 63;
+        *(u32x4*)(wl + t * 16) = *(const u32x4*)(w1 + (((l & 31) * 9 + tap) * 16 + 8 * (l >> 5)) * 2);
+    }
     u32x4 wa[3];
     first_weights_frag(w0, r, h, wa);
     Affine<DT, 1> aff1;
@@ -883,87 +944,173 @@ conv_first2_kernel(const float* __restrict__ img, const float* __restrict__ w0, 
         sc[e] = scale0[c];
         sh[e] = shift0[c];
     }
+    // first-layer pixel groups of this wave: group g = wave + TH * slot; 2 groups per patch row (columns 0..31,
+    // 32..63) and one last group for column 64 of all rows.  Source / destination offsets do not depend on the tile.
+    constexpr int NGRP = 2 * P1H + 1, NSLOT = (NGRP + TH - 1) / TH;
+    static_assert(P1W == 65 && P1H <= 32, "group layout of the first-layer patch");
+    int src_off[NSLOT], dst_off[NSLOT];
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {
+        const int g = min(wave + TH * sl, NGRP - 1);
+        const bool col = g == NGRP - 1;
+        const int py = col ? min(r, P1H - 1) : g >> 1, px = col ? P1W - 1 : (g & 1) * 32 + r;
+        src_off[sl] = (py * P0P + px + 2 * h) * 8;
+        dst_off[sl] = (py * P1W + (px & 1) * P1EVEN + (px >> 1)) * PS + 8 * h;
+    }
 
-    // ---- A: image patch, converted to bf16 once ------------------------------------------------
-    const int gy0 = 2 * oy0 - 2, gx0 = 2 * ox0 - 2;
-    // all loads of the wave's rows are issued before the first use (clamped, always valid addresses;
-    // positions outside the image are zeroed afterwards)
-    constexpr int NROW = (P0H + TH - 1) / TH;
-    float v[NROW][2][3];
+    // image patch of a tile: P0H x P0P pixels dealt to the threads in row-major order (NSL per thread), three
+    // colour planes each.  Offsets relative to the patch origin do not depend on the tile; a tile whose patch
+    // crosses the image border clamps every address (always valid) and zeroes those positions when it writes.
+    constexpr int NP0 = P0H * P0P, NSL = (NP0 + 64 * TH - 1) / (64 * TH);
+    int yx[NSL];           // patch row << 8 | patch column
 #pragma unroll
-    for (int i = 0; i < NROW; ++i) {
-        const int gy = min(max(gy0 + wave + i * TH, 0), H - 1);
-#pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            const int gx = min(max(gx0 + lane + 64 * part, 0), W - 1);
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                v[i][part][c] = (part == 0 || lane + 64 < P0P) ? img[(((size_t)b * 3 + c) * H + gy) * W + gx] : 0.0f;
-        }
+    for (int k = 0; k < NSL; ++k) {
+        const int idx = min(tid + 64 * TH * k, NP0 - 1);
+        const int iy = idx / P0P, ix = idx - iy * P0P;
+        yx[k] = iy << 8 | ix;
     }
+    float v[NSL][3];
+    const int plane = H * W;
+    auto is_border = [&](const First2Tile& t) {
+        const int gy0 = 2 * t.oy0 - 2, gx0 = 2 * t.ox0 - 2;
+        return gy0 < 0 || gy0 + P0H > H || gx0 < 0 || gx0 + P0P > W;
+    };
+    auto fetch = [&](const First2Tile& t) {
+        const int gy0 = 2 * t.oy0 - 2, gx0 = 2 * t.ox0 - 2;
+        const float* ib = img + (size_t)t.b * 3 * plane;
+        if (is_border(t)) {
 #pragma unroll
-    for (int i = 0; i < NROW; ++i) {
-        const int iy = wave + i * TH, gy = gy0 + iy;
+            for (int k = 0; k < NSL; ++k) {
+                const int gy = min(max(gy0 + (yx[k] >> 8), 0), H - 1), gx = min(max(gx0 + (yx[k] & 255), 0), W - 1);
 #pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            const int ix = lane + 64 * part, gx = gx0 + ix;
-            if (iy >= P0H || ix >= P0P) continue;
-            const bool in = gy >= 0 && gy < H && ix < P0W && gx >= 0 && gx < W;
-            const uint2 pk = make_uint2(f32x2_to_bf16x2(v[i][part][0], v[i][part][1]), f32x2_to_bf16x2(v[i][part][2], 0.0f));
-            *(uint2*)(p0 + (iy * P0P + ix) * 8) = in ? pk : make_uint2(0u, 0u);
+                for (int c = 0; c < 3; ++c) v[k][c] = ib[c * plane + gy * W + gx];
+            }
+        } else {
+            const float* org = ib + gy0 * W + gx0;
+#pragma unroll
+            for (int k = 0; k < NSL; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[k][c] = org[c * plane + (yx[k] >> 8) * W + (yx[k] & 255)];
         }
-    }
-    __syncthreads();
-    // ---- B: first layer into the bf16 patch -----------------------------------------------------
-    constexpr int NPIX = P1H * P1W, NGRP = (NPIX + 31) / 32;
-    for (int g = wave; g < NGRP; g += TH) {
-        const int q = g * 32 + r;
-        const int qq = q < NPIX ? q : NPIX - 1;
-        const int py = qq / P1W, px = qq - py * P1W;
-        const char* src = p0 + (py * P0P + px + 2 * h) * 8;
-        f32x16_t d;
+    };
+    // (a fetch is never conditional: a fixed number of loads in flight lets the compiler count them instead of
+    // draining the queue; a tile that does not exist fetches the pixels of tile (0, 0, 0), which nobody uses)
+    First2Tile item = first2_item(0, nitems, tiles_x, segs_y);
+    First2Tile cur = first2_step(item, 0, tiles_y);
+    fetch(cur);
+    F2_STAMP(1);
+
+    // first layer of two pixel groups at a time (independent accumulators keep the matrix pipe and the
+    // transcendental unit busy): slots s0 and s1 = s0 + 1 (s1 may not exist)
+    auto layer1 = [&](auto border_tag, int s0, bool has1, int gy0, int gx0) {
+        constexpr bool BORDER = decltype(border_tag)::value;
+        const int s1 = s0 + 1;
+        f32x16_t d0, d1;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) d[e] = 0.0f;
+        for (int e = 0; e < 16; ++e) d0[e] = d1[e] = 0.0f;
+        const char* q0 = p0 + src_off[s0];
+        const char* q1 = p0 + src_off[has1 ? s1 : s0];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const uint2 lo = *(const uint2*)(src + ky * P0P * 8), hi = *(const uint2*)(src + ky * P0P * 8 + 8);
-            mma_step<DT>(d, wa[ky], u32x4{lo.x, lo.y, hi.x, hi.y});
+            const uint2 lo0 = *(const uint2*)(q0 + ky * P0P * 8), hi0 = *(const uint2*)(q0 + ky * P0P * 8 + 8);
+            const uint2 lo1 = *(const uint2*)(q1 + ky * P0P * 8), hi1 = *(const uint2*)(q1 + ky * P0P * 8 + 8);
+            mma_step<DT>(d0, wa[ky], u32x4{lo0.x, lo0.y, hi0.x, hi0.y});
+            mma_step<DT>(d1, wa[ky], u32x4{lo1.x, lo1.y, hi1.x, hi1.y});
         }
-        float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = silu<DT>(d[e] * sc[e] + sh[e]);
-        const int gy = gy0 + 1 + py, gx = gx0 + 1 + px;
-        const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        uint2 pk0, pk1;
-        pk0.x = inside ? f32x2_to_bf16x2(o[0], o[1]) : 0u;
-        pk0.y = inside ? f32x2_to_bf16x2(o[2], o[3]) : 0u;
-        pk1.x = inside ? f32x2_to_bf16x2(o[4], o[5]) : 0u;
-        pk1.y = inside ? f32x2_to_bf16x2(o[6], o[7]) : 0u;
-        if (q < NPIX) {
-            char* dst = p1 + (py * P1W + (px & 1) * P1EVEN + (px >> 1)) * PS + 8 * h;
-            *(uint2*)dst = pk0;
-            *(uint2*)(dst + 16) = pk1;
+        for (int u = 0; u < 2; ++u) {
+            const int sl = u ? s1 : s0;
+            if (u && !has1) break;                            // wave-uniform
+            const f32x16_t& d = u ? d1 : d0;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = silu<DT>(d[e] * sc[e] + sh[e]);
+            uint2 pk0 = make_uint2(f32x2_to_bf16x2(o[0], o[1]), f32x2_to_bf16x2(o[2], o[3]));
+            uint2 pk1 = make_uint2(f32x2_to_bf16x2(o[4], o[5]), f32x2_to_bf16x2(o[6], o[7]));
+            const int g = wave + TH * sl;
+            const bool col = g == NGRP - 1;
+            bool live = !col || r < P1H;
+            if constexpr (BORDER) {                           // the second layer's zero padding
+                const int py = col ? min(r, P1H - 1) : g >> 1, px = col ? P1W - 1 : (g & 1) * 32 + r;
+                const int gy = gy0 + 1 + py, gx = gx0 + 1 + px;
+                if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) pk0 = pk1 = make_uint2(0u, 0u);
+            }
+            if (live) {
+                *(uint2*)(p1 + dst_off[sl]) = pk0;
+                *(uint2*)(p1 + dst_off[sl] + 16) = pk1;
+            }
         }
-    }
-    __syncthreads();
-    // ---- C: second layer ----------------------------------------------------------------------------
-    f32x16_t acc[1][1];
+    };
+
+    const int njobs = rounds * SEG;
+    for (int k = 0; j < njobs; ++j) {
+        if (++k == SEG) {           // the divisions of the item decode run once per SEG tiles
+            k = 0;
+            item = first2_item(j / SEG + 1, nitems, tiles_x, segs_y);
+            item.valid = item.valid && j + 1 < njobs;
+        }
+        const First2Tile nxt = first2_step(item, k, tiles_y);
+        if (!cur.valid) {           // workgroup-uniform: ragged ends of the item range and of a column of tiles
+            fetch(nxt);
+            cur = nxt;
+            continue;
+        }
+        const int b = cur.b, oy0 = cur.oy0, ox0 = cur.ox0;
+        const int gy0 = 2 * oy0 - 2, gx0 = 2 * ox0 - 2;
+        // ---- A: image patch, converted to bf16 once ------------------------------------------------
+        const bool border = is_border(cur);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.0f;
-    const int ty = wave;
+        for (int k = 0; k < NSL; ++k) {
+            const int iy = yx[k] >> 8, ix = yx[k] & 255;
+            bool in = ix < P0W;
+            if (border) {
+                const int gy = gy0 + iy, gx = gx0 + ix;
+                in = in && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            }
+            const uint2 pk = make_uint2(f32x2_to_bf16x2(v[k][0], v[k][1]), f32x2_to_bf16x2(v[k][2], 0.0f));
+            if (k + 1 < NSL || tid + 64 * TH * k < NP0) *(uint2*)(p0 + (iy * P0P + ix) * 8) = in ? pk : make_uint2(0u, 0u);
+        }
+        F2_STAMP(2);
+        __syncthreads();
+        F2_STAMP(3);
+        // the next tile's pixels travel while this one is computed
+        fetch(nxt);
+        // ---- B: first layer into the bf16 patch -----------------------------------------------------
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap % 3;
-        const u32x4 bb = *(const u32x4*)(p1 + ((2 * ty + ky) * P1W + (kx & 1) * P1EVEN + r + (kx >> 1)) * PS + 16 * h);
-        mma_step<DT>(acc[0][0], a[tap], bb);
+        for (int s0 = 0; s0 < NSLOT; s0 += 2) {
+            if (wave + TH * s0 >= NGRP) break;                                   // wave-uniform
+            const bool has1 = s0 + 1 < NSLOT && wave + TH * (s0 + 1) < NGRP;
+            if (border) layer1(std::true_type{}, s0, has1, gy0, gx0);
+            else layer1(std::false_type{}, s0, has1, gy0, gx0);
+        }
+        F2_STAMP(4);
+        __syncthreads();
+        F2_STAMP(5);
+        // ---- C: second layer ------------------------------------------------------------------------
+        f32x16_t acc[1][1];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.0f;
+        const int ty = wave;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const u32x4 aa = *(const u32x4*)(wl + (tap * 64 + lane) * 16);
+            const u32x4 bb = *(const u32x4*)(p1 + ((2 * ty + ky) * P1W + (kx & 1) * P1EVEN + r + (kx >> 1)) * PS + 16 * h);
+            mma_step<DT>(acc[0][0], aa, bb);
+        }
+        F2_STAMP(6);
+        __syncthreads();   // every wave is done reading the patch: its memory becomes the epilogue slices
+        F2_STAMP(7);
+        const int oy = oy0 + ty, ox = ox0 + r;
+        int opix[1] = {(oy < Ho && ox < Wo) ? oy * Wo + ox : -1};
+        if (ybytes)
+            nhwc_epilogue_fast<DT, 1, 1, true>(acc, opix, lds + wave * (32 * (128 + 16)), lane, 0, b * Ho * Wo, aff1, y, ybytes, y_ld);
+        else
+            nhwc_epilogue<DT, 1, 1>(acc, opix, lds + wave * (32 * (128 + 16)), lane, 0, (size_t)b * Ho * Wo, aff1, 32, y, y_ld, 1, 0);
+        F2_STAMP(8);
+        F2_STAMP_AT(9, 12);
+        cur = nxt;
     }
-    __syncthreads();   // every wave is done reading the patch: its memory becomes the epilogue slices
-    const int oy = oy0 + ty, ox = ox0 + r;
-    int opix[1] = {(oy < Ho && ox < Wo) ? oy * Wo + ox : -1};
-    if (ybytes)
-        nhwc_epilogue_fast<DT, 1, 1, true>(acc, opix, lds + wave * (32 * (128 + 16)), lane, 0, b * Ho * Wo, aff1, y, ybytes, y_ld);
-    else
-        nhwc_epilogue<DT, 1, 1>(acc, opix, lds + wave * (32 * (128 + 16)), lane, 0, (size_t)b * Ho * Wo, aff1, 32, y, y_ld, 1, 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1437,6 +1584,21 @@ int odamd_conv_first_forward(const float* image, const float* w, const float* sc
     return (int)hipGetLastError();
 }
 
+// Workgroups of conv_first2_kernel the current device keeps resident at once (0 on error); queried once per device.
+static int first2_resident_workgroups() {
+    static int cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cached[dev]) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_first2_kernel, 64 * first2::TH, first2::LDS_BYTES) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return 0;
+        cached[dev] = std::max(per_cu, 1) * cus / 8 * 8;
+    }
+    return cached[dev];
+}
+
 int odamd_conv_first2_forward(const float* image, const float* w0, const float* scale0, const float* shift0,
                               const void* w1, const float* scale1, const float* shift1, void* y, int batch, int h,
                               int w_in, int y_ld, void* stream) {
@@ -1445,12 +1607,22 @@ int odamd_conv_first2_forward(const float* image, const float* w0, const float* 
     if (y_ld < 32) return ODAMD_E_SHAPE;
     if (((uintptr_t)y & 15) || ((uintptr_t)w1 & 15) || (y_ld * 2) % 16) return ODAMD_E_ALIGN;
     const int ho = (h - 1) / 2 + 1, wo = (w_in - 1) / 2 + 1;
-    dim3 grid((wo + first2::TW - 1) / first2::TW, (ho + first2::TH - 1) / first2::TH, batch);
     static_assert(first2::LDS_BYTES <= 64 * 1024, "fits the default LDS limit of a workgroup");
     const size_t npix = (size_t)batch * ho * wo;
     const unsigned ybytes = fast_epilogue_ok(npix, y_ld, 2, 32, 32, 0) ? (unsigned)((npix - 1) * y_ld * 2 + 64) : 0u;
-    conv_first2_kernel<<<grid, 64 * first2::TH, first2::LDS_BYTES, (hipStream_t)stream>>>(
-        image, w0, scale0, shift0, (const char*)w1, scale1, shift1, (char*)y, h, w_in, ho, wo, y_ld, ybytes);
+    // persistent workgroups: as many as the device holds at once (a multiple of 8, one share per XCD)
+    const int tiles_x = (wo + first2::TW - 1) / first2::TW, tiles_y = (ho + first2::TH - 1) / first2::TH;
+    const int segs_y = (tiles_y + first2::SEG - 1) / first2::SEG;
+    const long long nitems_ll = (long long)batch * tiles_x * segs_y;
+    if (nitems_ll > (1ll << 30)) return ODAMD_E_SHAPE;
+    const int nitems = (int)nitems_ll, per_xcd = (nitems + 7) / 8;
+    int resident = first2_resident_workgroups();
+    if (resident < 8) return (int)hipErrorInvalidDevice;
+    const int slots = std::min(resident / 8, per_xcd);
+    const int rounds = (per_xcd + slots - 1) / slots;
+    conv_first2_kernel<<<slots * 8, 64 * first2::TH, first2::LDS_BYTES, (hipStream_t)stream>>>(
+        image, w0, scale0, shift0, (const char*)w1, scale1, shift1, (char*)y, h, w_in, ho, wo, y_ld, ybytes, nitems, tiles_x,
+        tiles_y, segs_y, rounds);
     return (int)hipGetLastError();
 }
 
