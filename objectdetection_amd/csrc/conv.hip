@@ -649,6 +649,7 @@ __global__ void __launch_bounds__(256) conv1x1_stream_kernel(StreamP p) {
 __device__ __attribute__((aligned(64))) const unsigned char g_zero_line[64] = {};
 
 #include "conv_dma.h"
+#include "conv_s3.h"
 
 // ------------------------------------------------------------------------------------------
 // first layer, float32 compute: float32 NCHW image, 3 input channels, 3x3 stride 1 -> NHWC
@@ -1111,6 +1112,7 @@ conv_first2_kernel(const float* __restrict__ img, const float* __restrict__ w0, 
         F2_STAMP_AT(9, 12);
         cur = nxt;
     }
+    F2_STAMP_AT(10, njobs);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1378,6 +1380,8 @@ int launch_stream(const ConvP& c, hipStream_t st) {
 // ---- LDS-DMA kernel: configuration, launch -------------------------------------------------------
 struct DmaConfig { int ks, pg, cg, wp, wc, ckb, nbuf; };
 #ifdef ODAMD_LAB
+static int g_lab_no_s3 = 0;
+struct S3Config;
 DmaConfig g_lab_force = {};      // tools/micro/conv_lab.hip tries instantiations through this
 #endif
 
@@ -1457,6 +1461,92 @@ int dispatch_dma(const ConvP& p, const DmaConfig& g, hipStream_t st) {
     LAB_DMA_VARIANTS
 #endif
 #undef ODAMD_DMA_CASE
+    return ODAMD_E_ARG;
+}
+
+// ---- persistent 3x3 kernel for the wide, shallow layers (conv_s3.h) --------------------------------------
+struct S3Config { int ksteps, cg, st, pg, npad_max, nbuf; };
+
+#ifdef ODAMD_LAB
+S3Config g_lab_s3 = {};
+#endif
+S3Config s3_config(const ConvP& p, int ks, int stride, int dtype) {
+    S3Config none = {};
+    if (dtype != ODAMD_DTYPE_BF16 || ks != 3 || p.pool || p.upz || p.nchw || p.accum || !p.scale || !p.shift) return none;
+#ifdef ODAMD_LAB
+    if (g_lab_no_s3) return none;
+#endif
+    const long long npix = (long long)p.B * p.Ho * p.Wo;
+    // measured at batch 64 (tools/micro/conv_lab.hip and the per-layer profile of the network): stride 1 is ahead of
+    // conv_igemm_kernel on the 320 x 320 map (0.25 -> 0.21 ms) and behind it on the 160 x 160 slices of the ELAN
+    // concat buffers (64 of every 256 bytes: both kernels drop to ~2.3 TB/s there, this one pays its ragged
+    // tile columns on top); stride 2 is ahead from 160 x 160 outputs up
+    if (npix < (stride == 1 ? 4 : 1) * 1024 * 1024) return none;
+    if (npix * p.y_ld * 2 >= (1ll << 31)) return none;   // 32-bit offsets of the buffer stores
+#ifdef ODAMD_LAB
+    if (g_lab_s3.pg) return g_lab_s3;
+#endif
+    if (stride == 1 && p.Cin == 32 && p.Cout == 32) return {2, 1, 1, 8, 384, 2};
+    if (stride == 2 && p.Cin == 32 && p.Cout == 64) return {2, 2, 2, 4, 640, 3};
+    return none;
+}
+
+template <int KSTEPS, int CG, int ST, int PG, int NPAD_MAX, int NBUF, bool ACT>
+int launch_s3(const ConvP& c, hipStream_t st) {
+    S3P p = {};
+    p.x = c.x; p.w = c.w; p.scale = c.scale; p.shift = c.shift; p.y = c.y;
+    p.H = c.H; p.W = c.W; p.Ho = c.Ho; p.Wo = c.Wo; p.x_ld = c.x_ld; p.y_ld = c.y_ld; p.act = c.act;
+    p.twl = p.Wo % 32 == 0 ? 5 : p.Wo % 16 == 0 ? 4 : p.Wo % 8 == 0 ? 3 : 5;
+    p.TW = 1 << p.twl;
+    p.TH = PG * 32 / p.TW;
+    p.IH = ST * (p.TH - 1) + 3;
+    p.IW = ST * (p.TW - 1) + 3;
+    p.IWH = p.TW + 1;
+    if (p.IH * (ST == 2 ? 2 * p.IWH : p.IW) > NPAD_MAX || p.IW > 255) return ODAMD_E_SHAPE;
+    p.npad = NPAD_MAX;          // fixed piece count per tile (the kernel's main loop has no branches)
+    p.tiles_x = (p.Wo + p.TW - 1) / p.TW;
+    p.tiles_y = (p.Ho + p.TH - 1) / p.TH;
+    p.segs_y = (p.tiles_y + S3_SEG - 1) / S3_SEG;
+    const long long nitems = (long long)c.B * p.tiles_x * p.segs_y;
+    if (nitems > (1ll << 28)) return ODAMD_E_SHAPE;
+    p.nitems = (int)nitems;
+    p.ybytes = (unsigned)(((size_t)c.B * p.Ho * p.Wo - 1) * p.y_ld * 2 + (size_t)c.Cout * 2);
+    const size_t lds = (size_t)CG * 9 * KSTEPS * 1024 + NBUF * (size_t)(2 * KSTEPS) * p.npad * 16;
+    auto k = conv_s3_kernel<KSTEPS, CG, ST, PG, NPAD_MAX, NBUF, ACT>;
+    static int resident[64];                 // workgroups the device keeps resident at once, per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+    if (!resident[dev]) {
+        // the largest patch this instantiation can be launched with sizes the occupancy (and the attribute)
+        const size_t lds_max = (size_t)CG * 9 * KSTEPS * 1024 + NBUF * (size_t)(2 * KSTEPS) * NPAD_MAX * 16;
+        if (lds_max > 160 * 1024) return ODAMD_E_SHAPE;
+        if (lds_max > 64 * 1024 &&
+            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess)
+            return (int)hipGetLastError();
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, lds_max) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1)
+            return (int)hipErrorInvalidDevice;
+        resident[dev] = per_cu * cus / 8 * 8;
+        if (resident[dev] < 8) { resident[dev] = 0; return (int)hipErrorInvalidDevice; }
+    }
+    const int per_xcd = (p.nitems + 7) / 8;
+    const int slots = std::min(resident[dev] / 8, per_xcd);
+    p.rounds = (per_xcd + slots - 1) / slots;
+    k<<<slots * 8, 256, lds, st>>>(p);
+    return (int)hipGetLastError();
+}
+
+int dispatch_s3(const ConvP& p, const S3Config& g, hipStream_t st) {
+#define ODAMD_S3_CASE(KSTEPS, CG, ST, PG, NPAD, NBUF)                                                          \
+    if (g.ksteps == KSTEPS && g.cg == CG && g.st == ST && g.pg == PG && g.npad_max == NPAD && g.nbuf == NBUF)  \
+        return p.act ? launch_s3<KSTEPS, CG, ST, PG, NPAD, NBUF, true>(p, st) : launch_s3<KSTEPS, CG, ST, PG, NPAD, NBUF, false>(p, st);
+    ODAMD_S3_CASE(2, 1, 1, 8, 384, 2)
+    ODAMD_S3_CASE(2, 2, 2, 4, 640, 3)
+#ifdef LAB_S3_VARIANTS
+    LAB_S3_VARIANTS
+#endif
+#undef ODAMD_S3_CASE
     return ODAMD_E_ARG;
 }
 
@@ -1545,6 +1635,12 @@ static int fill_conv_params(const odamd_conv_desc* d, ConvP* out, bool need_poin
 int odamd_conv_weight_layout(const odamd_conv_desc* d, int* cout_groups, int* chunk_bytes) {
     ConvP p;
     if (!cout_groups || !chunk_bytes || fill_conv_params(d, &p, false) != ODAMD_OK) return 0;
+    const S3Config s3 = s3_config(p, d->ksize, d->stride, d->dtype);
+    if (s3.pg) {                // the whole weight tensor as one block of fragments
+        *cout_groups = s3.cg;
+        *chunk_bytes = p.Cin * 2;
+        return 1;
+    }
     const DmaConfig g = dma_config(p, d->ksize, d->stride, d->dtype);
     if (!g.pg) return 0;
     *cout_groups = g.cg;
@@ -1558,6 +1654,8 @@ int odamd_conv_forward(const odamd_conv_desc* d, void* stream) {
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (d->w_packed) {
+        const S3Config s3 = s3_config(p, d->ksize, d->stride, d->dtype);
+        if (s3.pg) return dispatch_s3(p, s3, st);
         const DmaConfig g = dma_config(p, d->ksize, d->stride, d->dtype);
         if (!g.pg) return ODAMD_E_ARG;        // this layer has no packed-weight form (odamd_conv_weight_layout returned 0)
         return dispatch_dma(p, g, st);

@@ -52,6 +52,13 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 #undef ODAMD_W
 }
 
+// s_waitcnt vmcnt(N) with a compile-time N
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_imm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // upper bound of staged input pixels per workgroup (the host tile chooser enforces it)
 __host__ __device__ constexpr int dma_max_in_pix(int ks, int pg) { return ks == 1 ? 32 * pg : (pg >= 8 ? 384 : 256); }
 

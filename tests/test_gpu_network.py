@@ -62,6 +62,13 @@ BLOCK_CASES = [
     ('cbs', dict(in_=256, out_=256, kernel_size=1, stride=1), (1, 256, 192, 192)),
     ('cbs', dict(in_=32, out_=64, kernel_size=1, stride=1), (3, 32, 120, 120)),
     ('cbs', dict(in_=96, out_=40, kernel_size=1, stride=1), (1, 96, 200, 170)),
+    # >= 2^22 (stride 1) / 2^20 (stride 2) output pixels, 32 input channels: the persistent 3x3 kernel (tile widths 32 / 8 / ragged 32, stride 1
+    # and 2 with its even / odd column planes, ragged bottom tiles, item ranges that do not divide by 8)
+    ('cbs', dict(in_=32, out_=32, kernel_size=3, stride=1), (41, 32, 320, 320)),
+    ('cbs', dict(in_=32, out_=32, kernel_size=3, stride=1), (20, 32, 500, 424)),
+    ('cbs', dict(in_=32, out_=32, kernel_size=3, stride=1), (35, 32, 348, 348)),
+    ('cbs', dict(in_=32, out_=64, kernel_size=3, stride=2), (11, 32, 640, 640)),
+    ('cbs', dict(in_=32, out_=64, kernel_size=3, stride=2), (6, 32, 870, 810)),
     ('elan', dict(in_=16, out_=32, n=1), (2, 16, 12, 12)),
     ('elan', dict(in_=32, out_=64, n=2), (1, 32, 16, 16)),
     ('elan_h', dict(in_=64, out_=32), (2, 64, 8, 8)),

@@ -8,6 +8,9 @@
     ODAMD_DMA_CASE(3, 4, 2, 4, 1, 32, 3) ODAMD_DMA_CASE(3, 4, 4, 2, 2, 32, 2) ODAMD_DMA_CASE(3, 8, 4, 4, 2, 32, 2) \
     ODAMD_DMA_CASE(3, 8, 4, 4, 2, 32, 3) ODAMD_DMA_CASE(1, 4, 4, 2, 2, 128, 2) ODAMD_DMA_CASE(1, 8, 4, 2, 2, 128, 2) ODAMD_DMA_CASE(1, 4, 4, 2, 2, 64, 2) \
     ODAMD_DMA_CASE(1, 8, 4, 4, 2, 64, 3) ODAMD_DMA_CASE(1, 8, 8, 4, 2, 64, 2) ODAMD_DMA_CASE(1, 8, 4, 4, 2, 128, 2)
+#define LAB_S3_VARIANTS \
+    ODAMD_S3_CASE(2, 1, 1, 4, 256, 3) ODAMD_S3_CASE(2, 1, 1, 4, 256, 4) ODAMD_S3_CASE(2, 1, 1, 8, 384, 3) \
+    ODAMD_S3_CASE(2, 2, 2, 4, 640, 2)
 #include "../../objectdetection_amd/csrc/conv.hip"
 
 #include <cstdio>
@@ -41,6 +44,7 @@ int main(int argc, char** argv) {
         {"3x3s2 32->64 @320", 320, 32, 64, 3, 2, 0},
     };
     const int only = argc > 1 ? atoi(argv[1]) : -1;
+    const int ldmul = argc > 2 ? atoi(argv[2]) : 1;      // x_ld = ldmul * cin, y_ld = ldmul * cout (slices of wider tensors)
     size_t max_in = 0, max_out = 0, max_w = 0;
     for (auto& c : cases) {
         const int ho = c.pool ? c.h / 2 : (c.s == 2 ? c.h / 2 : c.h);
@@ -50,17 +54,17 @@ int main(int argc, char** argv) {
     }
     uint16_t *x, *w, *y;
     float *sc, *sh;
-    hipMalloc(&x, max_in * 2);
-    hipMalloc(&y, max_out * 2);
+    hipMalloc(&x, max_in * 2 * ldmul);
+    hipMalloc(&y, max_out * 2 * ldmul);
     hipMalloc(&w, max_w * 2);
     hipMalloc(&sc, 4096 * 4);
     hipMalloc(&sh, 4096 * 4);
     {
-        std::vector<uint16_t> hx(max_in), hw(max_w);
+        std::vector<uint16_t> hx(max_in * ldmul), hw(max_w);
         srand(1);
         for (auto& v : hx) v = bf((rand() % 2001 - 1000) * 1e-3f);
         for (auto& v : hw) v = bf((rand() % 2001 - 1000) * 3e-5f);
-        hipMemcpy(x, hx.data(), max_in * 2, hipMemcpyHostToDevice);
+        hipMemcpy(x, hx.data(), max_in * 2 * ldmul, hipMemcpyHostToDevice);
         hipMemcpy(w, hw.data(), max_w * 2, hipMemcpyHostToDevice);
         std::vector<float> one(4096, 1.0f), zero(4096, 0.01f);
         hipMemcpy(sc, one.data(), 4096 * 4, hipMemcpyHostToDevice);
@@ -71,7 +75,7 @@ int main(int argc, char** argv) {
     hipEventCreate(&e1);
     uint16_t *wp_dev, *y2;
     hipMalloc(&wp_dev, max_w * 2 * 2);
-    hipMalloc(&y2, max_out * 2);
+    hipMalloc(&y2, max_out * 2 * ldmul);
     std::vector<uint16_t> hw(max_w);
     hipMemcpy(hw.data(), w, max_w * 2, hipMemcpyDeviceToHost);
     double total = 0, total_new = 0;
@@ -95,7 +99,7 @@ int main(int argc, char** argv) {
         odamd_conv_desc d = {};
         d.x = x; d.w = w; d.scale = sc; d.shift = sh; d.y = y;
         d.batch = B; d.h = c.h; d.w_in = c.h; d.cin = c.cin; d.cout = c.cout;
-        d.x_ld = c.cin; d.y_ld = c.cout; d.ksize = c.k; d.stride = c.s; d.act = 1; d.dtype = ODAMD_DTYPE_BF16;
+        d.x_ld = c.cin * ldmul; d.y_ld = c.cout * ldmul; d.ksize = c.k; d.stride = c.s; d.act = 1; d.dtype = ODAMD_DTYPE_BF16;
         d.in_pool2 = c.pool;
         int rc = 0, rc2 = 0;
         const double us = time_it(d, &rc);
@@ -107,15 +111,23 @@ int main(int argc, char** argv) {
         printf("%2zu %-20s rc=%d %7.2f us %6.1f TF/s %6.0f GB/s ideal %6.2f frac %.2f |", ci, c.name, rc, us, flops / us * 1e-6,
                bytes / us * 1e-3, ideal, ideal / us);
         static const DmaConfig variants[] = {
+            {0, 0, 0, 0, 0, 0, 0},          // the library's own choice of a packed-weight kernel, if it has one
+            {-1, 4, 256, 3, 0, 0, 0}, {-1, 4, 256, 4, 0, 0, 0}, {-1, 8, 384, 3, 0, 0, 0}, {-2, 4, 640, 2, 0, 0, 0},   // conv_s3 variants: pg, npad, nbuf
             {3, 8, 2, 4, 1, 64, 2}, {3, 8, 2, 4, 1, 32, 3}, {3, 8, 2, 4, 1, 32, 2}, {3, 4, 2, 2, 2, 32, 3}, {3, 4, 2, 4, 1, 32, 3},
             {3, 4, 4, 2, 2, 32, 2}, {3, 8, 4, 4, 2, 32, 2}, {3, 8, 4, 4, 2, 32, 3}, {1, 8, 4, 2, 2, 128, 2}, {1, 4, 4, 2, 2, 128, 2},
             {1, 4, 4, 2, 2, 64, 3}, {1, 4, 4, 2, 2, 64, 2}, {1, 8, 4, 4, 2, 64, 3}, {1, 8, 8, 4, 2, 64, 2}, {1, 8, 4, 4, 2, 128, 2}};
         double best = us;
         for (const DmaConfig& v : variants) {
-            if (v.ks != c.k || c.s != 1 || c.pool) continue;
+            if (v.ks > 0 && (v.ks != c.k || c.s != 1 || c.pool)) continue;
+            if (v.ks > 0 && only < 0) continue;     // the full sweep only with a case selected
+            g_lab_s3 = {};
+            if (v.ks < 0) {
+                if (c.k != 3 || c.cin != 32 || c.s != -v.ks || c.cout != 32 * c.s) continue;
+                g_lab_s3 = {2, c.s, c.s, v.pg, v.cg, v.wp};
+            } else
             g_lab_force = v;
             int G = 0, CB = 0;
-            if (!odamd_conv_weight_layout(&d, &G, &CB)) { g_lab_force = {}; continue; }
+            if (!odamd_conv_weight_layout(&d, &G, &CB)) { g_lab_force = {}; g_lab_s3 = {}; continue; }
             const int T = c.k * c.k, ncb = (c.cout + 32 * G - 1) / (32 * G), nch = c.cin * 2 / CB, KSN = CB / 32;
             std::vector<uint16_t> pk((size_t)ncb * nch * G * T * KSN * 512, 0);
             size_t o = 0;
@@ -128,11 +140,14 @@ int main(int argc, char** argv) {
             hipMemcpy(wp_dev, pk.data(), pk.size() * 2, hipMemcpyHostToDevice);
             odamd_conv_desc d2 = d;
             d2.w = wp_dev; d2.y = y2; d2.w_packed = 1;
-            hipMemset(y2, 0xFF, (size_t)B * ho * ho * c.cout * 2);
+            hipMemset(y2, 0, (size_t)B * ho * ho * c.cout * 2 * ldmul);
+            hipMemset(y, 0, (size_t)B * ho * ho * c.cout * 2 * ldmul);
+            { int rcx; time_it(d, &rcx); }
             int rc2 = 0;
             const double us2 = time_it(d2, &rc2);
             g_lab_force = {};
-            const size_t n = (size_t)B * ho * ho * c.cout;
+            g_lab_s3 = {};
+            const size_t n = (size_t)B * ho * ho * c.cout * ldmul;
             std::vector<uint16_t> a(n), b2(n);
             hipMemcpy(a.data(), y, n * 2, hipMemcpyDeviceToHost);
             hipMemcpy(b2.data(), y2, n * 2, hipMemcpyDeviceToHost);
@@ -145,6 +160,19 @@ int main(int argc, char** argv) {
                 if (!(df <= maxdiff)) maxdiff = df;
             }
 #ifdef ODAMD_LAB_STAMPS
+            if (v.ks <= 0 && c.cin == 32) {
+                static std::vector<unsigned long long> st(1024 * 8 * 16);
+                hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_lab_stamps), st.size() * 8);
+                const char* nm[6] = {"top", "wait", "barrier", "issue", "mma", "epi"};
+                for (int blk : {0, 77, 300})
+                    for (int wv : {0, 3}) {
+                        const unsigned long long* q = &st[(blk * 8 + wv) * 16];
+                        printf("\n      blk %3d wave %d:", blk, wv);
+                        for (int i = 1; i < 6; ++i) printf(" %s=%lld", nm[i], (long long)(q[i] - q[i - 1]));
+                        printf(" tile=%lld", (long long)(q[5] - q[0]));
+                    }
+                printf("\n     ");
+            } else if (v.ks > 0)
             {
                 static std::vector<unsigned long long> st(1024 * 8 * 16);
                 hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_lab_stamps), st.size() * 8);

@@ -48,6 +48,12 @@ int main(int argc, char** argv) {
     static std::vector<unsigned long long> st(1024 * 8 * 16);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_lab_stamps), st.size() * 8);
     const char* nm[9] = {"start", "issue", "imgwait+lds", "barA", "B", "barB", "C", "barC", "epi"};
+    {
+        unsigned long long lo = ~0ull, hi = 0, life = 0; int late = 0, nb = 0;
+        for (int blk = 0; blk < 1024; ++blk) { const unsigned long long* q = &st[(blk * 8) * 16]; if (!q[0]) continue; ++nb; if (q[0] < lo) lo = q[0]; if (q[10] > hi) hi = q[10]; life += q[10] - q[0]; }
+        for (int blk = 0; blk < 1024; ++blk) { const unsigned long long* q = &st[(blk * 8) * 16]; if (q[0] && q[0] > lo + 50000) ++late; }
+        printf("blocks %d span %llu cycles, mean life %llu, late starters %d\n", nb, hi - lo, life / (nb ? nb : 1), late);
+    }
     for (int blk : {0, 3, 7})
         for (int wv : {0, 3}) {
             const unsigned long long* q = &st[(blk * 8 + wv) * 16];
