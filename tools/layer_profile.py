@@ -1,7 +1,8 @@
 """Per-layer device time of one YOLOv7 forward (HIP events); prints a table."""
+import os
 import sys
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from objectdetection_amd import engine
 from objectdetection_amd.model.yolov7 import yolov7
 from oracle import patterns

@@ -12,19 +12,8 @@ import re
 import sys
 
 
-def family(name):
-    m = re.search(r'conv1x1_stream_kernel<(\d+), (\d+),', name)
-    if m:
-        return 'conv1x1_s1_%s' % {1: 'c32', 2: 'c64', 4: 'c128'}[int(m.group(2))]
-    m = re.search(r'conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+),', name)
-    if m:
-        _, ks, st, cg = (int(v) for v in m.groups())
-        return 'conv%dx%d_s%d_%s' % (ks, ks, st, {1: 'c32', 2: 'c64', 4: 'c128'}[cg])
-    for key in ('conv_first2_kernel', 'conv_first_kernel', 'iou_mask_win_kernel', 'iou_mask_kernel', 'emit_heads_kernel', 'area_order_kernel', 'nms_scan_kernel', 'filter_kernel',
-                'emit_rows_kernel', 'bitonic_lds_kernel', 'bitonic_global_kernel', 'spp_pool3_kernel'):
-        if key in name:
-            return key
-    return None
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+from kernel_family import family          # noqa: E402
 
 
 def main():

@@ -17,15 +17,12 @@ def load(path):
     return d
 
 
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+from kernel_family import family as _family          # noqa: E402
+
+
 def family(name):
-    m = re.search(r'conv1x1_stream_kernel<(\d+), (\d+),', name)
-    if m:
-        return 'conv1x1_s1_%s' % {1: 'c32', 2: 'c64', 4: 'c128'}[int(m.group(2))]
-    m = re.search(r'conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+),', name)
-    if not m:
-        return None
-    _, ks, st, cg = (int(v) for v in m.groups())
-    return 'conv%dx%d_s%d_%s' % (ks, ks, st, {1: 'c32', 2: 'c64', 4: 'c128'}[cg])
+    return _family(name, conv_only=True)
 
 
 def main():
