@@ -650,6 +650,7 @@ __device__ __attribute__((aligned(64))) const unsigned char g_zero_line[64] = {}
 
 #include "conv_dma.h"
 #include "conv_s3.h"
+#include "conv_wres.h"
 
 // ------------------------------------------------------------------------------------------
 // first layer, float32 compute: float32 NCHW image, 3 input channels, 3x3 stride 1 -> NHWC
@@ -1550,6 +1551,82 @@ int dispatch_s3(const ConvP& p, const S3Config& g, hipStream_t st) {
     return ODAMD_E_ARG;
 }
 
+// ---- persistent 1x1 kernel with register-resident weights (conv_wres.h) ------------------------------------
+struct WresConfig { int kch, cgw, nbuf; };
+
+#ifdef ODAMD_LAB
+static int g_lab_no_wres = 0;
+WresConfig g_lab_wres = {};
+#endif
+WresConfig wres_config(const ConvP& p, int ks, int stride, int dtype) {
+    WresConfig none = {};
+    if (dtype != ODAMD_DTYPE_BF16 || ks != 1 || stride != 1 || p.pool || p.upz || p.nchw || p.accum || !p.scale || !p.shift)
+        return none;
+#ifdef ODAMD_LAB
+    if (g_lab_no_wres) return none;
+#endif
+    const long long npix = (long long)p.B * p.H * p.W;
+    if (npix < 64 * 64 || npix * p.y_ld * 2 >= (1ll << 31) || npix >= (1ll << 24)) return none;
+    if (p.Cout % 128) return none;
+    int nbuf = 3;
+#ifdef ODAMD_LAB
+    if (g_lab_wres.nbuf) nbuf = g_lab_wres.nbuf;
+    if (g_lab_wres.cgw == 1 && (p.Cin == 256 || p.Cin == 512)) return {p.Cin / 256, 1, nbuf};
+#endif
+    if (p.Cin == 256) return {1, p.Cout % 256 == 0 ? 2 : 1, nbuf};
+    if (p.Cin == 512) return {2, p.Cout % 256 == 0 ? 2 : 1, nbuf};
+    if (p.Cin == 1024) return {4, 1, nbuf};
+    return none;
+}
+
+template <int KCH, int CGW, int NBUF, bool ACT>
+int launch_wres(const ConvP& c, hipStream_t st) {
+    WresP p = {};
+    p.x = c.x; p.w = c.w; p.scale = c.scale; p.shift = c.shift; p.y = c.y;
+    p.npix = c.B * c.H * c.W; p.x_ld = c.x_ld; p.y_ld = c.y_ld; p.Cout = c.Cout;
+    p.ntiles = (p.npix + 63) / 64;
+    p.ncb = c.Cout / (128 * CGW);
+    p.ybytes = (unsigned)(((size_t)p.npix - 1) * p.y_ld * 2 + (size_t)c.Cout * 2);
+    const size_t lds = (size_t)NBUF * WRES_UNIT + 2 * 128 * CGW * sizeof(float);
+    auto k = conv1x1_wres_kernel<KCH, CGW, NBUF, ACT>;
+    static int cus[64];                      // compute units per device; one workgroup each (the ring fills the LDS)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+    if (!cus[dev]) {
+        if (lds > 160 * 1024) return ODAMD_E_SHAPE;
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return (int)hipGetLastError();
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return (int)hipErrorInvalidDevice;
+        cus[dev] = n / 8 * 8;
+    }
+    // walkers: a multiple of 8 (one share per XCD), at most one workgroup per compute unit, no more than tiles
+    int nwalk = cus[dev] / p.ncb / 8 * 8;
+    if (nwalk < 8) return ODAMD_E_SHAPE;
+    const int need = (p.ntiles + 7) / 8 * 8;
+    if (nwalk > need) nwalk = need;
+    p.nwalk = nwalk;
+    p.rounds = ((p.ntiles + nwalk - 1) / nwalk + 1) & ~1;
+    k<<<nwalk * p.ncb, 256, lds, st>>>(p);
+    return (int)hipGetLastError();
+}
+
+int dispatch_wres(const ConvP& p, const WresConfig& g, hipStream_t st) {
+#define ODAMD_WRES_CASE(KCH, CGW, NBUF)                                                            \
+    if (g.kch == KCH && g.cgw == CGW && g.nbuf == NBUF)                                            \
+        return p.act ? launch_wres<KCH, CGW, NBUF, true>(p, st) : launch_wres<KCH, CGW, NBUF, false>(p, st);
+    ODAMD_WRES_CASE(1, 2, 3)
+    ODAMD_WRES_CASE(1, 1, 3)
+    ODAMD_WRES_CASE(2, 2, 3)
+    ODAMD_WRES_CASE(2, 1, 3)
+    ODAMD_WRES_CASE(4, 1, 3)
+#ifdef LAB_WRES_VARIANTS
+    LAB_WRES_VARIANTS
+#endif
+#undef ODAMD_WRES_CASE
+    return ODAMD_E_ARG;
+}
+
 template <int DT>
 int dispatch_conv(const ConvP& p, int ks, int stride, hipStream_t st) {
     const int cin_bytes = p.Cin * Elem<DT>::SIZE;
@@ -1641,6 +1718,12 @@ int odamd_conv_weight_layout(const odamd_conv_desc* d, int* cout_groups, int* ch
         *chunk_bytes = p.Cin * 2;
         return 1;
     }
+    const WresConfig wr = wres_config(p, d->ksize, d->stride, d->dtype);
+    if (wr.kch) {               // the whole reduction of a block of 128 * cgw output channels as one block of fragments
+        *cout_groups = 4 * wr.cgw;
+        *chunk_bytes = p.Cin * 2;
+        return 1;
+    }
     const DmaConfig g = dma_config(p, d->ksize, d->stride, d->dtype);
     if (!g.pg) return 0;
     *cout_groups = g.cg;
@@ -1656,6 +1739,8 @@ int odamd_conv_forward(const odamd_conv_desc* d, void* stream) {
     if (d->w_packed) {
         const S3Config s3 = s3_config(p, d->ksize, d->stride, d->dtype);
         if (s3.pg) return dispatch_s3(p, s3, st);
+        const WresConfig wr = wres_config(p, d->ksize, d->stride, d->dtype);
+        if (wr.kch) return dispatch_wres(p, wr, st);
         const DmaConfig g = dma_config(p, d->ksize, d->stride, d->dtype);
         if (!g.pg) return ODAMD_E_ARG;        // this layer has no packed-weight form (odamd_conv_weight_layout returned 0)
         return dispatch_dma(p, g, st);

@@ -42,6 +42,8 @@ int main(int argc, char** argv) {
         {"1x1 128->128 @160", 160, 128, 128, 1, 1, 0}, {"3x3 32->32 @160", 160, 32, 32, 3, 1, 0},
         {"1x1p 128->64 @160", 160, 128, 64, 1, 1, 1},  {"3x3 32->32 @320", 320, 32, 32, 3, 1, 0},
         {"3x3s2 32->64 @320", 320, 32, 64, 3, 2, 0},
+        {"1x1 256->128 @80", 80, 256, 128, 1, 1, 0},  {"1x1 512->256 @40", 40, 512, 256, 1, 1, 0},
+        {"1x1 256->256 @20", 20, 256, 256, 1, 1, 0},
     };
     const int only = argc > 1 ? atoi(argv[1]) : -1;
     const int ldmul = argc > 2 ? atoi(argv[2]) : 1;      // x_ld = ldmul * cin, y_ld = ldmul * cout (slices of wider tensors)
@@ -112,6 +114,8 @@ int main(int argc, char** argv) {
                bytes / us * 1e-3, ideal, ideal / us);
         static const DmaConfig variants[] = {
             {0, 0, 0, 0, 0, 0, 0},          // the library's own choice of a packed-weight kernel, if it has one
+            {-3, 0, 0, 0, 0, 0, 0},         // without the register-resident 1x1 kernel (the LDS-DMA kernel's own choice)
+            {-4, 1, 0, 0, 0, 0, 0},         // register-resident 1x1 kernel with one channel group per wave
             {-1, 4, 256, 3, 0, 0, 0}, {-1, 4, 256, 4, 0, 0, 0}, {-1, 8, 384, 3, 0, 0, 0}, {-2, 4, 640, 2, 0, 0, 0},   // conv_s3 variants: pg, npad, nbuf
             {3, 8, 2, 4, 1, 64, 2}, {3, 8, 2, 4, 1, 32, 3}, {3, 8, 2, 4, 1, 32, 2}, {3, 4, 2, 2, 2, 32, 3}, {3, 4, 2, 4, 1, 32, 3},
             {3, 4, 4, 2, 2, 32, 2}, {3, 8, 4, 4, 2, 32, 2}, {3, 8, 4, 4, 2, 32, 3}, {1, 8, 4, 2, 2, 128, 2}, {1, 4, 4, 2, 2, 128, 2},
@@ -121,13 +125,20 @@ int main(int argc, char** argv) {
             if (v.ks > 0 && (v.ks != c.k || c.s != 1 || c.pool)) continue;
             if (v.ks > 0 && only < 0) continue;     // the full sweep only with a case selected
             g_lab_s3 = {};
+            g_lab_no_wres = 0;
+            g_lab_wres = {};
+            if (v.ks == -3 || v.ks == -4) {
+                if (c.k != 1 || c.pool) continue;
+                if (v.ks == -3) g_lab_no_wres = 1; else g_lab_wres = {0, 1, 0};
+            } else
             if (v.ks < 0) {
                 if (c.k != 3 || c.cin != 32 || c.s != -v.ks || c.cout != 32 * c.s) continue;
                 g_lab_s3 = {2, c.s, c.s, v.pg, v.cg, v.wp};
             } else
             g_lab_force = v;
             int G = 0, CB = 0;
-            if (!odamd_conv_weight_layout(&d, &G, &CB)) { g_lab_force = {}; g_lab_s3 = {}; continue; }
+            if (v.ks > 0) g_lab_no_wres = 1;
+            if (!odamd_conv_weight_layout(&d, &G, &CB)) { g_lab_force = {}; g_lab_s3 = {}; g_lab_no_wres = 0; g_lab_wres = {}; continue; }
             const int T = c.k * c.k, ncb = (c.cout + 32 * G - 1) / (32 * G), nch = c.cin * 2 / CB, KSN = CB / 32;
             std::vector<uint16_t> pk((size_t)ncb * nch * G * T * KSN * 512, 0);
             size_t o = 0;
@@ -147,6 +158,8 @@ int main(int argc, char** argv) {
             const double us2 = time_it(d2, &rc2);
             g_lab_force = {};
             g_lab_s3 = {};
+            g_lab_no_wres = 0;
+            g_lab_wres = {};
             const size_t n = (size_t)B * ho * ho * c.cout * ldmul;
             std::vector<uint16_t> a(n), b2(n);
             hipMemcpy(a.data(), y, n * 2, hipMemcpyDeviceToHost);
@@ -186,7 +199,7 @@ int main(int argc, char** argv) {
                 printf("\n     ");
             }
 #endif
-            printf(" [%d,%d,%d,%d,%d,%d]", v.pg, v.cg, v.wp, v.wc, v.ckb, v.nbuf);
+            printf(" [%s%d,%d,%d,%d,%d,%d]", v.ks == -3 ? "dma:" : v.ks == -4 ? "wres1:" : "", v.pg, v.cg, v.wp, v.wc, v.ckb, v.nbuf);
             if (rc2) printf(" rc=%d", rc2); else printf(" %.1f%s", us2, maxdiff > 0.02 ? "(BAD)" : "");
             if (!rc2 && maxdiff <= 0.02 && us2 < best) best = us2;
         }
