@@ -1566,7 +1566,8 @@ WresConfig wres_config(const ConvP& p, int ks, int stride, int dtype) {
     if (g_lab_no_wres) return none;
 #endif
     const long long npix = (long long)p.B * p.H * p.W;
-    if (npix < 64 * 64 || npix * p.y_ld * 2 >= (1ll << 31) || npix >= (1ll << 24)) return none;
+    // whole 64-pixel tiles only (the kernel has no ragged tile); 32-bit byte offsets in the buffer stores
+    if (npix < 1024 || npix % 64 || npix * p.y_ld * 2 >= (1ll << 31) || npix >= (1ll << 24)) return none;
     if (p.Cout % 128) return none;
     int nbuf = 3;
 #ifdef ODAMD_LAB
@@ -1587,7 +1588,7 @@ int launch_wres(const ConvP& c, hipStream_t st) {
     p.ntiles = (p.npix + 63) / 64;
     p.ncb = c.Cout / (128 * CGW);
     p.ybytes = (unsigned)(((size_t)p.npix - 1) * p.y_ld * 2 + (size_t)c.Cout * 2);
-    const size_t lds = (size_t)NBUF * WRES_UNIT + 2 * 128 * CGW * sizeof(float);
+    const size_t lds = (size_t)NBUF * WRES_UNIT + 2 * 128 * CGW * sizeof(float) + 4 * 32 * (CGW * 64 + 16);
     auto k = conv1x1_wres_kernel<KCH, CGW, NBUF, ACT>;
     static int cus[64];                      // compute units per device; one workgroup each (the ring fills the LDS)
     int dev = 0;

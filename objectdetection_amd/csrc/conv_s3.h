@@ -186,13 +186,19 @@ __global__ void __launch_bounds__(256) conv_s3_kernel(S3P p) {
     constexpr int NG = TAPS * KSTEPS;
     // vector-memory instructions issued after the last piece of a tile until its wait: those of D - 1 whole iterations
     // (stores after the last piece within its own iteration are left out, which only makes the wait stricter)
+    // That count assumes D - 1 whole iterations behind the tile's pieces; the first D tiles of a workgroup have
+    // fewer (and the stores of the tile "before the first" fail the range check and retire at once, ahead of older
+    // loads), so they wait for the pieces alone: stricter is always safe.  The choice is a branch at the head of a
+    // tile, where the wait and the barrier end the scheduling region anyway.
     constexpr int WAITN = (D - 1) * (MAXJ + NST);
-    int bi = 0;
+    int bi = 0, warm = 0;
     S3Tile prev = {0, 0, 0, false};
     auto body = [&](f32x16_t (&ac)[PGW][CG], const f32x16_t (&ap)[PGW][CG], int j) {
         const S3Tile cur = q[0];
         S3_STAMP(0);
-        wait_vmcnt_imm<WAITN>();              // this wave's pieces of the tile have landed
+        if (warm >= D) wait_vmcnt_imm<WAITN>();     // this wave's pieces of the tile have landed
+        else wait_vmcnt_imm<(D - 1) * MAXJ>();
+        ++warm;
         S3_STAMP(1);
         __builtin_amdgcn_s_barrier();         // ... and everybody else's; the buffer of the previous tile is free
         S3_STAMP(2);

@@ -15,10 +15,10 @@
 //     copies 8 pixels x 128 contiguous bytes (whole cache lines); in LDS the lanes land as
 //     [pixel / 8][16-byte part][pixel % 8] with one spare part per row of 8 pixels, which makes every ds_read_b128
 //     pass of a B fragment (32 consecutive pixels of one part) hit 16 distinct bank groups;
-//   * the epilogue needs no LDS and no separate phase: affine + SiLU + bf16 + v_permlane32_swap + one 16-byte
-//     buffer store per 8 accumulator values (as in conv_s3_kernel), spread between the matrix instructions of the
-//     NEXT tile's first unit (two accumulator sets alternate), so vector, matrix and memory work overlap inside one
-//     wave.  The affine constants sit in LDS (the registers belong to the weights).
+//   * the epilogue is no separate phase: affine + SiLU + bf16 of a tile's results are spread between the matrix
+//     instructions of the NEXT tile's first unit (two accumulator sets alternate), so vector, matrix and memory work
+//     overlap inside one wave.  The bf16 results pass through a small wave-private LDS area so that every store
+//     instruction writes whole 128-byte runs per pixel.
 // Workgroups with the same pixel walk and different channel blocks are neighbours on one XCD (block b and b + 8),
 // so the second reader of a tile finds it in that XCD's L2.
 
@@ -68,7 +68,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             for (int ch = 0; ch < KCH; ++ch)
 #pragma unroll
                 for (int s = 0; s < KS16; ++s) A[ch][j][s] = *(const u32x4*)(wb + ((size_t)(j * KCH + ch) * KS16 + s) * 1024);
-#ifndef WRES_NO_PIN
         // The weights only ever feed matrix instructions, which read the accumulation half of the register file
         // directly; the results are post-processed by vector instructions, which cannot.  Steer the allocation
         // accordingly (otherwise every result is copied out of that half one register at a time).
@@ -78,7 +77,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             for (int ch = 0; ch < KCH; ++ch)
 #pragma unroll
                 for (int s = 0; s < KS16; ++s) asm volatile("" : "+a"(A[ch][j][s]));
-#endif
     }
     for (int t = tid; t < 128 * CGW; t += 256) {
         aff[t] = p.scale[cbase + t];
@@ -134,6 +132,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // makes the compiler drain the vector-memory queue first.)  Kept in registers where the weights leave room,
     // otherwise fetched from LDS one pair of epilogue units ahead of their use.
     constexpr bool AFF_REGS = KCH * CGW <= 2;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     auto load_aff = [&](int sl, u32x4 (&v)[4]) {
         const char* ab = (const char*)aff + (wave * 32 * CGW + 16 * sl + 4 * h) * 4;
         v[0] = *(const u32x4*)ab; v[1] = *(const u32x4*)(ab + 32);
@@ -156,52 +155,66 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         load_aff(0, affn);
     }
 
-    // Epilogue unit u = (channel group jc, half qh, pixel group i) of tile `tile`: see conv_s3_kernel.
-    auto epi_unit = [&](int u, const f32x16_t (&ac)[PGW][CGW], int tile) {
-        const int i = u % PGW, jc = (u / PGW) / 2, qh = (u / PGW) % 2;
-        const int pix = tile * 64 + 32 * i + r;
-        const bool ok = tile >= 0 && pix < p.npix;
-        float sc[8], sh[8];
+    // Epilogue of a tile in NH half-slots and PGW flushes.  Half-slot hs = (pixel group i, 16-channel slice k = 2 jc + qh,
+    // half q): affine + SiLU of 4 accumulator values, bf16, one 8-byte write into the wave's transposition area
+    // [32 pixels][64 CGW channels].  After the last half-slot of a pixel group the flush reads the area back 16 bytes
+    // per lane, 4 CGW lanes per pixel, and stores whole 128-byte (CGW = 2) or 64-byte runs per pixel: a store
+    // instruction covers 8 or 16 pixel rows completely instead of 32-byte pieces of 32 rows.  LDS operations of one
+    // wave execute in order, so the area needs no barrier.  The half-slots are dealt evenly to the k-steps of the
+    // next tile's first unit, so every k-step carries the same vector work beside its matrix instructions.
+    constexpr int SLICES = CGW * 2, NH = PGW * SLICES * 2;
+    constexpr int TROW = CGW * 64 + 16;                        // bytes per pixel in the transposition area
+    constexpr int LPP = CGW * 4, PPP = 64 / LPP, PASSES = 32 / PPP;
+    static_assert(PGW * PASSES == NU, "one store instruction per 8 accumulator values");
+    static_assert(KS16 % NH == 0 || NH % KS16 == 0, "half-slots spread evenly over the k-steps");
+    char* tarea = (char*)(aff + 2 * 128 * CGW) + wave * (32 * TROW);
+    auto epi_half = [&](int hs, const f32x16_t (&ac)[PGW][CGW], int tile) {
+        const int i = hs / (SLICES * 2), k = (hs / 2) % SLICES, q2 = hs % 2;
+        const int jc = k / 2, qh = k % 2;
+        float sc[4], sh[4];
         if constexpr (AFF_REGS) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { sc[e] = affr[jc * 2 + qh][e]; sh[e] = affr[jc * 2 + qh][8 + e]; }
+            for (int e = 0; e < 4; ++e) { sc[e] = affr[k][4 * q2 + e]; sh[e] = affr[k][8 + 4 * q2 + e]; }
         } else {
-            // one pair of units ahead: the unit of pixel group 0 fetches the constants of the NEXT channel slice
-            if (i == 0) {
+            if (q2 == 0) {   // the constants of the NEXT slice are fetched one slot ahead of their use
 #pragma unroll
                 for (int e = 0; e < 4; ++e) affc[e] = affn[e];
-                load_aff(((u / PGW) + 1) % (CGW * 2), affn);
+                load_aff((k + 1) % SLICES, affn);
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sc[e] = __uint_as_float(affc[0][e]); sc[4 + e] = __uint_as_float(affc[1][e]);
-                sh[e] = __uint_as_float(affc[2][e]); sh[4 + e] = __uint_as_float(affc[3][e]);
-            }
+            for (int e = 0; e < 4; ++e) { sc[e] = __uint_as_float(affc[q2][e]); sh[e] = __uint_as_float(affc[2 + q2][e]); }
         }
-        uint32_t pk[4];
+        uint32_t pk[2];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int e = 8 * qh + 2 * m;
+        for (int m = 0; m < 2; ++m) {
+            const int e = 8 * qh + 4 * q2 + 2 * m;
             float t0 = ac[i][jc][e] * sc[2 * m] + sh[2 * m], t1 = ac[i][jc][e + 1] * sc[2 * m + 1] + sh[2 * m + 1];
             if (ACT) { t0 = silu<DT>(t0); t1 = silu<DT>(t1); }
             pk[m] = f32x2_to_bf16x2(t0, t1);
         }
-        const auto w0 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
-        const auto w1 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
-        const u32x4 out = u32x4{w0[0], w1[0], w0[1], w1[1]};
-#ifdef LAB_WRES_NOSTORE
-        const int voff = (ok && out[0] == 0x12345678u) ? (pix * p.y_ld + cw0 + 32 * jc + 16 * qh + 8 * h) * 2 : -1;
-#else
-        const int voff = ok ? (pix * p.y_ld + cw0 + 32 * jc + 16 * qh + 8 * h) * 2 : -1;
-#endif
-        __builtin_amdgcn_raw_buffer_store_b128(out, rsrc, voff, 0, 0);
+        // channels 16 k + 8 q2 + 4 h + (0 .. 3) of pixel r
+        *(u32x2*)(tarea + r * TROW + (16 * k + 8 * q2 + 4 * h) * 2) = u32x2{pk[0], pk[1]};
+        if (hs % (SLICES * 2) == SLICES * 2 - 1) {             // the pixel group is complete: flush it
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int px = ps * PPP + lane / LPP, part = lane % LPP;
+                const u32x4 out = *(const u32x4*)(tarea + px * TROW + part * 16);
+                const int pix = tile * 64 + 32 * i + px;
+                const bool ok = (unsigned)pix < (unsigned)p.npix;      // also false for the tile "-1" before the first one
+                const int voff = ok ? (pix * p.y_ld + cw0) * 2 + part * 16 : -1;
+                __builtin_amdgcn_raw_buffer_store_b128(out, rsrc, voff, 0, 0);
+            }
+        }
     };
 
     // Counted wait at the head of a unit: every vector-memory instruction this wave issued after the unit's last
     // DMA piece may still be outstanding.  Those are the pieces of the D - 1 units issued since, plus the NU stores
     // of every first unit of a tile among the D - 1 units processed since (the stores of a tile go out during the
     // first unit of the next one).  During the first D units of a workgroup fewer stores have been issued than the
-    // steady-state count assumes, so they wait for the pieces alone (stricter is always safe).
+    // steady-state count assumes, so they wait for the pieces alone (stricter is always safe).  The choice is a
+    // branch at the head of a unit, where the wait and the barrier end the scheduling region anyway.
+    // (Stores that only exist to be counted must not be used to even this out: a store whose offset fails the range
+    // check of the buffer resource retires at once, ahead of older loads.)
     int bi = 0, prev_tile = -1, warm = 0;
     // One tile: KCH units.  `ac` receives the tile, `ap` holds the previous tile's results for the epilogue.
     auto body = [&](f32x16_t (&ac)[PGW][CGW], const f32x16_t (&ap)[PGW][CGW]) {
@@ -234,7 +247,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 for (int k = s * MAXJ / KS16; k < (s + 1) * MAXJ / KS16; ++k) issue_piece(k, inc, nbuf);
                 if (ch == 0) {
 #pragma unroll
-                    for (int u = s * NU / KS16; u < (s + 1) * NU / KS16; ++u) epi_unit(u, ap, prev_tile);
+                    for (int hs = s * NH / KS16; hs < (s + 1) * NH / KS16; ++hs) epi_half(hs, ap, prev_tile);
                 }
 #pragma unroll
                 for (int i = 0; i < PGW; ++i)
@@ -264,5 +277,5 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         body(accB, accA);
     }
 #pragma unroll
-    for (int u = 0; u < NU; ++u) epi_unit(u, accB, prev_tile);
+    for (int hs = 0; hs < NH; ++hs) epi_half(hs, accB, prev_tile);
 }

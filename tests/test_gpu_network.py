@@ -56,6 +56,15 @@ BLOCK_CASES = [
     ('cbs', dict(in_=512, out_=256, kernel_size=1, stride=1), (4, 512, 20, 20)),
     ('cbs', dict(in_=256, out_=136, kernel_size=1, stride=1), (3, 256, 19, 21)),
     ('cbs', dict(in_=1024, out_=256, kernel_size=1, stride=1), (2, 1024, 20, 20)),
+    # 256 / 512 / 1024 input channels, output channels in multiples of 128, pixel count a multiple of 64: the persistent
+    # 1x1 kernel with register-resident weights (1..3 channel blocks, one and two channel groups per wave, fewer tiles
+    # than workgroups, odd tile counts, several rounds per workgroup)
+    ('cbs', dict(in_=256, out_=128, kernel_size=1, stride=1), (3, 256, 40, 40)),
+    ('cbs', dict(in_=512, out_=512, kernel_size=1, stride=1), (5, 512, 32, 32)),
+    ('cbs', dict(in_=512, out_=128, kernel_size=1, stride=1), (4, 512, 40, 40)),
+    ('cbs', dict(in_=1024, out_=256, kernel_size=1, stride=1), (4, 1024, 32, 32)),
+    ('cbs', dict(in_=256, out_=384, kernel_size=1, stride=1), (2, 256, 64, 64)),
+    ('cbs', dict(in_=256, out_=256, kernel_size=1, stride=1), (16, 256, 80, 80)),
     # >= 32768 pixels: the persistent streaming 1x1 kernel (ragged last tile, 1..2 channel blocks, partial chunk)
     ('cbs', dict(in_=64, out_=32, kernel_size=1, stride=1), (2, 64, 128, 128)),
     ('cbs', dict(in_=128, out_=128, kernel_size=1, stride=1), (2, 128, 128, 130)),
@@ -151,12 +160,13 @@ def test_whole_network_vs_reference_fixture(od, golden, dtype):
 
 
 def test_network_640_bf16_vs_f32_oracle(od):
-    """Full-size input (640^2, 80 classes, batch 2): bf16 path against the CPU fp32 oracle."""
+    """Full-size input (640^2, 80 classes, batch 4: every map has a multiple of 64 pixels, so the deep 1x1 layers take the
+    register-resident-weights kernel on slices of the concat buffers): bf16 path against the CPU fp32 oracle."""
     engine, layer, ymod = od
     args = patterns.default_args(input_size=640, output_class=80)
     net = ymod.yolov7(args)
     patterns.fill_state_dict(net)
-    x = patterns.image_batch(2, 640)
+    x = patterns.image_batch(4, 640)
     sd = {k: v.clone() for k, v in net.state_dict().items()}
     with torch.no_grad():
         ref = network.yolov7_forward(sd, x, args).numpy()
@@ -167,7 +177,7 @@ def test_network_640_bf16_vs_f32_oracle(od):
             got = net(x.cuda()).cpu().numpy()
         finally:
             engine.set_compute_dtype(None)
-        assert got.shape == (2, 25200, 85)
+        assert got.shape == (4, 25200, 85)
         assert rel_err(got[..., :4], ref[..., :4]) < TOL[dtype], (dtype, rel_err(got[..., :4], ref[..., :4]))
         assert rel_err(got[..., 4:], ref[..., 4:]) < TOL[dtype], (dtype, rel_err(got[..., 4:], ref[..., 4:]))
 

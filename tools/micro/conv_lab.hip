@@ -11,6 +11,7 @@
 #define LAB_S3_VARIANTS \
     ODAMD_S3_CASE(2, 1, 1, 4, 256, 3) ODAMD_S3_CASE(2, 1, 1, 4, 256, 4) ODAMD_S3_CASE(2, 1, 1, 8, 384, 3) \
     ODAMD_S3_CASE(2, 2, 2, 4, 640, 2)
+#define LAB_WRES_VARIANTS ODAMD_WRES_CASE(1, 2, 4) ODAMD_WRES_CASE(1, 1, 4) ODAMD_WRES_CASE(1, 2, 2) ODAMD_WRES_CASE(2, 2, 2) ODAMD_WRES_CASE(2, 1, 4) ODAMD_WRES_CASE(2, 1, 2)
 #include "../../objectdetection_amd/csrc/conv.hip"
 
 #include <cstdio>
@@ -116,6 +117,7 @@ int main(int argc, char** argv) {
             {0, 0, 0, 0, 0, 0, 0},          // the library's own choice of a packed-weight kernel, if it has one
             {-3, 0, 0, 0, 0, 0, 0},         // without the register-resident 1x1 kernel (the LDS-DMA kernel's own choice)
             {-4, 1, 0, 0, 0, 0, 0},         // register-resident 1x1 kernel with one channel group per wave
+            {-5, 4, 0, 0, 0, 0, 0}, {-5, 2, 0, 0, 0, 0, 0},   // ... with 4 / 2 ring buffers
             {-1, 4, 256, 3, 0, 0, 0}, {-1, 4, 256, 4, 0, 0, 0}, {-1, 8, 384, 3, 0, 0, 0}, {-2, 4, 640, 2, 0, 0, 0},   // conv_s3 variants: pg, npad, nbuf
             {3, 8, 2, 4, 1, 64, 2}, {3, 8, 2, 4, 1, 32, 3}, {3, 8, 2, 4, 1, 32, 2}, {3, 4, 2, 2, 2, 32, 3}, {3, 4, 2, 4, 1, 32, 3},
             {3, 4, 4, 2, 2, 32, 2}, {3, 8, 4, 4, 2, 32, 2}, {3, 8, 4, 4, 2, 32, 3}, {1, 8, 4, 2, 2, 128, 2}, {1, 4, 4, 2, 2, 128, 2},
@@ -127,9 +129,10 @@ int main(int argc, char** argv) {
             g_lab_s3 = {};
             g_lab_no_wres = 0;
             g_lab_wres = {};
-            if (v.ks == -3 || v.ks == -4) {
+            if (v.ks == -3 || v.ks == -4 || v.ks == -5) {
                 if (c.k != 1 || c.pool) continue;
-                if (v.ks == -3) g_lab_no_wres = 1; else g_lab_wres = {0, 1, 0};
+                if (v.ks == -5 && ((c.cin != 256 && c.cin != 512) || (c.cin == 512 && v.pg == 4 && c.cout % 256 == 0))) continue;
+                if (v.ks == -3) g_lab_no_wres = 1; else if (v.ks == -4) g_lab_wres = {0, 1, 0}; else g_lab_wres = {0, 0, v.pg};
             } else
             if (v.ks < 0) {
                 if (c.k != 3 || c.cin != 32 || c.s != -v.ks || c.cout != 32 * c.s) continue;
@@ -199,7 +202,7 @@ int main(int argc, char** argv) {
                 printf("\n     ");
             }
 #endif
-            printf(" [%s%d,%d,%d,%d,%d,%d]", v.ks == -3 ? "dma:" : v.ks == -4 ? "wres1:" : "", v.pg, v.cg, v.wp, v.wc, v.ckb, v.nbuf);
+            printf(" [%s%d,%d,%d,%d,%d,%d]", v.ks == -3 ? "dma:" : v.ks == -4 ? "wres1:" : v.ks == -5 ? "nbuf:" : "", v.pg, v.cg, v.wp, v.wc, v.ckb, v.nbuf);
             if (rc2) printf(" rc=%d", rc2); else printf(" %.1f%s", us2, maxdiff > 0.02 ? "(BAD)" : "");
             if (!rc2 && maxdiff <= 0.02 && us2 < best) best = us2;
         }
