@@ -965,13 +965,18 @@ iou_mask_win_kernel(const float4* __restrict__ sbox, const float4* __restrict__ 
     }
 }
 
-constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_GROUP = 256;                       // threads that share a tile's update: one column word each
+constexpr int SCAN_GROUPS = 2;                        // thread groups; group g owns the tiles t with t % SCAN_GROUPS == g
+constexpr int SCAN_THREADS = SCAN_GROUP * SCAN_GROUPS;
 
 // One workgroup per image.  `removed` (n_pad bits) lives in LDS for the chunk and in global
-// memory between chunks.  Per 64-row tile: wave 0 resolves the tile serially from its 64
-// diagonal words (uniform scalar work; the words of the NEXT tile are already in flight), then
-// all threads OR the kept rows' words into the later part of `removed`, eight rows per batch
-// of independent loads.
+// memory between chunks.  Per 64-row tile: the first wave of the owning group resolves the tile serially
+// from its 64 diagonal words (uniform scalar work), then the group's threads OR the kept rows' words into
+// the later part of `removed`.  The greedy order makes the tiles a serial chain, and a tile's mask words
+// cannot be consumed before it is resolved, so what bounds the chain is how far ahead they were requested:
+// every group loads the rows of ITS next tile (64 words per thread) right after finishing a tile, i.e.
+// SCAN_GROUPS tiles before they are needed, and the memory latency of one group hides behind the tiles
+// of the others.
 __global__ void __launch_bounds__(SCAN_THREADS)
 nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int* __restrict__ count,
                 const int* __restrict__ srow, u64* __restrict__ removed_g, int n_pad, int row_begin, int row_end,
@@ -989,29 +994,33 @@ nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int*
     for (int w = threadIdx.x; w < nwords; w += SCAN_THREADS) removed[w] = rg[w];
     if (threadIdx.x == 0) kept_total = keep_count[b];
     __syncthreads();
+    const int group = threadIdx.x / SCAN_GROUP, w0 = threadIdx.x % SCAN_GROUP;
     const int lane = threadIdx.x & 63;
+    const bool resolver = w0 < 64;                    // first wave of the group
     const int t_begin = row_begin >> 6;
     const int t_end = (min(row_end, n) + 63) >> 6;
+    // this group's next tile: the first one at or after t_begin with t % SCAN_GROUPS == group
+    int mine = t_begin + (group - t_begin % SCAN_GROUPS + SCAN_GROUPS) % SCAN_GROUPS;
     u64 diag_next = 0;
-    if (threadIdx.x < 64) {
-        const int i = t_begin * 64 + lane;
-        diag_next = (i < n) ? m[(size_t)(i - row_begin) * words + t_begin] : 0ull;
-    }
-    const int w0 = threadIdx.x;
     u64 v[64];
-    if (w0 > t_begin && w0 < nwords) {
-        const u64* m0 = m + (size_t)(t_begin * 64 - row_begin) * words;
+    auto fetch = [&](int t) {                          // diagonal words and row words of tile t (wave-uniform t)
+        if (t >= t_end) return;
+        if (resolver) {
+            const int i = t * 64 + lane;
+            diag_next = (i < n) ? m[(size_t)(i - row_begin) * words + t] : 0ull;
+        }
+        if (w0 > t && w0 < nwords) {
+            const u64* m0 = m + (size_t)(t * 64 - row_begin) * words;
 #pragma unroll
-        for (int u = 0; u < 64; ++u) v[u] = m0[(size_t)u * words + w0];
-    }
+            for (int u = 0; u < 64; ++u) v[u] = m0[(size_t)u * words + w0];
+        }
+    };
+    fetch(mine);
     for (int t = t_begin; t < t_end; ++t) {
-        if (threadIdx.x < 64) {
+        const bool owner = t == mine;                  // uniform within a group
+        if (owner && resolver) {
             const int i = t * 64 + lane;
             const u64 diag = diag_next;
-            if (t + 1 < t_end) {   // prefetch the next tile's diagonal words
-                const int i2 = i + 64;
-                diag_next = (i2 < n) ? m[(size_t)(i2 - row_begin) * words + t + 1] : 0ull;
-            }
             const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
             const u64 rem = removed[t];
             // wave-uniform state in scalar registers: the 64-step chain below is scalar work
@@ -1040,35 +1049,33 @@ nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int*
             }
         }
         __syncthreads();
-        const u64 kept = kept_bits;
-        const u64* mt = m + (size_t)(t * 64 - row_begin) * words;
-        // column word w0 = threadIdx.x: its 64 row words of this tile were loaded before the tile was
-        // resolved (the loads do not depend on the outcome: rows that were not kept are masked out)
-        if (w0 > t && w0 < nwords) {
-            u64 acc = 0;
+        if (owner) {
+            const u64 kept = kept_bits;
+            const u64* mt = m + (size_t)(t * 64 - row_begin) * words;
+            // column word w0: its 64 row words of this tile were loaded SCAN_GROUPS tiles ago (the loads do not
+            // depend on the outcome: rows that were not kept are masked out)
+            if (w0 > t && w0 < nwords) {
+                u64 acc = 0;
 #pragma unroll
-            for (int u = 0; u < 64; ++u) acc |= ((kept >> u) & 1ull) ? v[u] : 0ull;
-            removed[w0] |= acc;
-        }
-        // further column words (more than 16384 candidates): loaded here, two batches of 32
-        for (int w = w0 + SCAN_THREADS; w < nwords; w += SCAN_THREADS) {
-            if (w <= t) continue;
-            u64 acc = 0;
-#pragma unroll
-            for (int q0 = 0; q0 < 64; q0 += 32) {
-                u64 x[32];
-#pragma unroll
-                for (int u = 0; u < 32; ++u) x[u] = mt[(size_t)(q0 + u) * words + w];
-#pragma unroll
-                for (int u = 0; u < 32; ++u) acc |= ((kept >> (q0 + u)) & 1ull) ? x[u] : 0ull;
+                for (int u = 0; u < 64; ++u) acc |= ((kept >> u) & 1ull) ? v[u] : 0ull;
+                removed[w0] |= acc;
             }
-            removed[w] |= acc;
-        }
-        // the next tile's rows: in flight while that tile is being resolved
-        if (t + 1 < t_end && w0 > t + 1 && w0 < nwords) {
-            const u64* mn = mt + (size_t)64 * words;
+            // further column words (more than 16384 candidates): loaded here, four batches of 16
+            for (int w = w0 + SCAN_GROUP; w < nwords; w += SCAN_GROUP) {
+                if (w <= t) continue;
+                u64 acc = 0;
+#pragma unroll 1
+                for (int q0 = 0; q0 < 64; q0 += 16) {
+                    u64 x[16];
 #pragma unroll
-            for (int u = 0; u < 64; ++u) v[u] = mn[(size_t)u * words + w0];
+                    for (int u = 0; u < 16; ++u) x[u] = mt[(size_t)(q0 + u) * words + w];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) acc |= ((kept >> (q0 + u)) & 1ull) ? x[u] : 0ull;
+                }
+                removed[w] |= acc;
+            }
+            mine += SCAN_GROUPS;
+            fetch(mine);                               // in flight while the other groups' tiles are processed
         }
         __syncthreads();
     }
