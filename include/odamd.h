@@ -189,8 +189,10 @@ typedef struct {
 
 int odamd_conv_forward(const odamd_conv_desc* d, void* stream);
 
-/* Deep stride-1 bf16 layers on small maps are served by a kernel that moves its operands global -> LDS
- * without registers and wants the weights in the order its matrix fragments are read.  Returns 1 and sets
+/* Several bf16 layer classes are served by kernels that want the weights in the order their matrix fragments
+ * are read: deep stride-1 layers on small maps (operands global -> LDS without registers), the 32-channel 3x3
+ * layers on the largest maps (persistent, weights resident in LDS) and 1x1 layers with 256 / 512 / 1024 input
+ * channels (persistent, weights resident in registers: one chunk = the whole reduction).  Returns 1 and sets
  * (cout_groups G, chunk_bytes CB) when such a form exists for the layer `d` describes (pointers in `d` are
  * ignored), else 0.  Packed layout, T = ksize^2 taps, cout padded with zero rows to a multiple of 32*G,
  * cin*2 a multiple of CB:
