@@ -202,6 +202,16 @@ int odamd_conv_forward(const odamd_conv_desc* d, void* stream);
  * model/layer.py:12-16). */
 int odamd_conv_weight_layout(const odamd_conv_desc* d, int* cout_groups, int* chunk_bytes);
 
+/* The two 1x1 cbs blocks at the head of an mp block in ONE launch (mp.forward, model/layer.py:139-145: cbs1 on
+ * maxpool0(x), cbs2 on x): both read the same tensor, the largest of the block, which this entry point fetches
+ * once.  `pooled` describes cbs1 (in_pool2 = 1, output at half resolution), `plain` cbs2; both must name the same
+ * input (x, batch, h, w_in, cin, x_ld), bf16, plain weights, SiLU.  The fused form exists for whole 8 x 16 patches
+ * (h % 8 == 0, w_in % 16 == 0), 32 / 64 / 128 input channels and 32 / 64 / 128 output channels per branch:
+ * odamd_conv_mp_supported returns 1 then (pointers are ignored by the query), and odamd_conv_mp_forward gives the
+ * same results as the two odamd_conv_forward calls.  Otherwise the forward call returns ODAMD_E_SHAPE. */
+int odamd_conv_mp_supported(const odamd_conv_desc* pooled, const odamd_conv_desc* plain);
+int odamd_conv_mp_forward(const odamd_conv_desc* pooled, const odamd_conv_desc* plain, void* stream);
+
 /* First layer: float32 NCHW image (B,3,H,W) -> NHWC activations; replaces cbs0 of
  * yolov7.forward (model/yolov7.py:114).  w: [cout][ky][kx][3] float32; scale/shift may both be
  * NULL (raw convolution for train-mode BatchNorm); act: 0 none, 1 SiLU. */

@@ -651,6 +651,7 @@ __device__ __attribute__((aligned(64))) const unsigned char g_zero_line[64] = {}
 #include "conv_dma.h"
 #include "conv_s3.h"
 #include "conv_wres.h"
+#include "conv_mp.h"
 
 // ------------------------------------------------------------------------------------------
 // first layer, float32 compute: float32 NCHW image, 3 input channels, 3x3 stride 1 -> NHWC
@@ -1628,6 +1629,68 @@ int dispatch_wres(const ConvP& p, const WresConfig& g, hipStream_t st) {
     return ODAMD_E_ARG;
 }
 
+// ---- both 1x1 convolutions of an mp block in one launch (conv_mp.h) -------------------------------------------
+// Does the fused form exist for this pair?  `a`: the pooled branch (in_pool2), `b`: the plain branch of the same input.
+bool mp_pair_ok(const odamd_conv_desc* a, const odamd_conv_desc* b) {
+    if (!a || !b) return false;
+    if (a->dtype != ODAMD_DTYPE_BF16 || b->dtype != ODAMD_DTYPE_BF16) return false;
+    if (a->ksize != 1 || b->ksize != 1 || a->stride != 1 || b->stride != 1) return false;
+    if (!a->in_pool2 || b->in_pool2 || a->out_nchw_f32 || b->out_nchw_f32 || a->in_upzero2 || b->in_upzero2 || a->accumulate ||
+        b->accumulate || a->w_packed || b->w_packed || a->act != 1 || b->act != 1)
+        return false;
+    if (a->x != b->x || a->batch != b->batch || a->h != b->h || a->w_in != b->w_in || a->cin != b->cin || a->x_ld != b->x_ld) return false;
+    if (a->h % 8 || a->w_in % 16) return false;
+    const int cb = a->cin * 2;
+    if (cb != 64 && cb != 128 && cb != 256) return false;
+    auto couts_ok = [](int c) { return c == 32 || c == 64 || c == 128; };
+    if (!couts_ok(a->cout) || !couts_ok(b->cout)) return false;
+    const long long npix = (long long)a->batch * a->h * a->w_in;
+    if (npix * b->y_ld * 2 >= (1ll << 31) || (npix / 4) * a->y_ld * 2 >= (1ll << 31) || npix >= (1ll << 26)) return false;
+    if (a->y_ld < a->cout || b->y_ld < b->cout || (a->y_ld * 2) % 16 || (b->y_ld * 2) % 16 || (a->x_ld * 2) % 16) return false;
+    return true;
+}
+
+template <int CG2, int CG1, int NPF>
+int launch_mp(const odamd_conv_desc* a, const odamd_conv_desc* b, hipStream_t st) {
+    constexpr int WC = CG2 >= 2 ? 2 : 1, CGW = CG2 / WC;
+    MpP p = {};
+    p.x = (const char*)a->x;
+    p.w2 = (const char*)b->w; p.scale2 = b->scale; p.shift2 = b->shift; p.y2 = (char*)b->y;
+    p.w1 = (const char*)a->w; p.scale1 = a->scale; p.shift1 = a->shift; p.y1 = (char*)a->y;
+    p.B = a->batch; p.H = a->h; p.W = a->w_in; p.Cin = a->cin; p.x_ld = a->x_ld;
+    p.y2_ld = b->y_ld; p.y1_ld = a->y_ld; p.Cout2 = b->cout; p.Cout1 = a->cout;
+    p.tiles_x = p.W / 16; p.tiles_y = p.H / 8; p.ntiles = p.B * p.tiles_x * p.tiles_y;
+    const size_t npix = (size_t)p.B * p.H * p.W;
+    p.y2bytes = (unsigned)((npix - 1) * p.y2_ld * 2 + (size_t)p.Cout2 * 2);
+    p.y1bytes = (unsigned)((npix / 4 - 1) * p.y1_ld * 2 + (size_t)p.Cout1 * 2);
+    const size_t rsb = (size_t)p.Cin * 2 + 16;
+    size_t in_bytes = 128 * rsb;
+    const size_t epi = (size_t)4 * 32 * (CGW * 128 + 16);
+    if (in_bytes < epi) in_bytes = epi;
+    p.pool_off = (int)((in_bytes + 255) & ~(size_t)255);
+    p.w2_off = p.pool_off + (int)((32 * rsb + 255) & ~(size_t)255);
+    p.w1_off = p.w2_off + (int)(32 * CG2 * rsb);
+    const size_t lds = p.w1_off + 32 * CG1 * rsb;
+    auto k = conv_mp_kernel<CG2, CG1, NPF>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return (int)hipGetLastError();
+    int grid = lds <= 80 * 1024 ? 512 : 256;
+    if (grid > p.ntiles) grid = p.ntiles;
+    k<<<grid, 256, lds, st>>>(p);
+    return (int)hipGetLastError();
+}
+
+int dispatch_mp(const odamd_conv_desc* a, const odamd_conv_desc* b, hipStream_t st) {
+    const int cg2 = b->cout / 32, cg1 = a->cout / 32, npf = a->cin * 2 / 32;
+#define ODAMD_MP_CASE(CG2, CG1, NPF) if (cg2 == CG2 && cg1 == CG1 && npf == NPF) return launch_mp<CG2, CG1, NPF>(a, b, st);
+#define ODAMD_MP_CASES(CG2, CG1) ODAMD_MP_CASE(CG2, CG1, 2) ODAMD_MP_CASE(CG2, CG1, 4) ODAMD_MP_CASE(CG2, CG1, 8)
+    ODAMD_MP_CASES(1, 1) ODAMD_MP_CASES(2, 2) ODAMD_MP_CASES(4, 4)
+    ODAMD_MP_CASES(1, 2) ODAMD_MP_CASES(2, 1) ODAMD_MP_CASES(2, 4) ODAMD_MP_CASES(4, 2) ODAMD_MP_CASES(1, 4) ODAMD_MP_CASES(4, 1)
+#undef ODAMD_MP_CASES
+#undef ODAMD_MP_CASE
+    return ODAMD_E_SHAPE;
+}
+
 template <int DT>
 int dispatch_conv(const ConvP& p, int ks, int stride, hipStream_t st) {
     const int cin_bytes = p.Cin * Elem<DT>::SIZE;
@@ -1748,6 +1811,22 @@ int odamd_conv_forward(const odamd_conv_desc* d, void* stream) {
     }
     return d->dtype == ODAMD_DTYPE_F32 ? dispatch_conv<ODAMD_DTYPE_F32>(p, d->ksize, d->stride, st)
                                        : dispatch_conv<ODAMD_DTYPE_BF16>(p, d->ksize, d->stride, st);
+}
+
+int odamd_conv_mp_supported(const odamd_conv_desc* pooled, const odamd_conv_desc* plain) {
+    ConvP pa, pb;
+    if (fill_conv_params(pooled, &pa, false) != ODAMD_OK || fill_conv_params(plain, &pb, false) != ODAMD_OK) return 0;
+    return mp_pair_ok(pooled, plain) ? 1 : 0;
+}
+
+int odamd_conv_mp_forward(const odamd_conv_desc* pooled, const odamd_conv_desc* plain, void* stream) {
+    ConvP pa, pb;
+    int rc = fill_conv_params(pooled, &pa, true);
+    if (rc) return rc;
+    if ((rc = fill_conv_params(plain, &pb, true))) return rc;
+    if (!mp_pair_ok(pooled, plain)) return ODAMD_E_SHAPE;
+    if (((uintptr_t)pooled->y & 15) || ((uintptr_t)plain->y & 15)) return ODAMD_E_ALIGN;
+    return dispatch_mp(pooled, plain, (hipStream_t)stream);
 }
 
 int odamd_conv_first_forward(const float* image, const float* w, const float* scale, const float* shift, void* y,

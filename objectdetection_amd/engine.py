@@ -23,6 +23,7 @@ from . import _lib
 from ._lib import lib, check
 
 F32, BF16 = 0, 1
+FUSE_MP = True                # both 1x1 convolutions of an mp block in one launch (bf16 plans)
 FUSE_FIRST2 = True     # bf16 plans run cbs0 + cbs1 as one launch when the widths are 16 and 32
 _TORCH_DT = {0: torch.float32, 1: torch.bfloat16}
 CH_ALIGN = 16            # channel granule of buffer slices in bf16 plans (f32 plans use 8)
@@ -211,7 +212,8 @@ class Plan:
         self._fuse_sibling_convs()
         used = set()
         for op in builder.ops:      # buffers no launch touches any more (fused away) are not allocated
-            for a in [op.get('x'), op.get('y')] + list(op.get('ys', [])):
+            parts = [op['pooled'], op['plain']] if op['kind'] == 'mp2' else [op]
+            for a in [q.get(n) for q in parts for n in ('x', 'y')] + list(op.get('ys', [])):
                 if a is not None and not (op['kind'] == 'first2' and a is op.get('x')):
                     used.add(a.buf)
         self.bufs = [torch.zeros((builder.batch, h, w, c) if i in used else (0, h, w, c), dtype=dt, device=builder.device)
@@ -240,8 +242,35 @@ class Plan:
                 out.append(a)
                 i += 1
         out = self._fuse_first_two(out)
+        out = self._fuse_mp_pairs(out)
         self.b.ops = out
-        self.b.convs = [op for op in out if op['kind'] in ('conv', 'head', 'first', 'first2')]
+        self.b.convs = []
+        for op in out:
+            if op['kind'] in ('conv', 'head', 'first', 'first2'):
+                self.b.convs.append(op)
+            elif op['kind'] == 'mp2':
+                self.b.convs += [op['pooled'], op['plain']]
+
+    def _fuse_mp_pairs(self, ops):
+        """cbs1 (on the max-pooled input) and cbs2 (on the input itself) of an mp block (model/layer.py:139-145) read
+        the same tensor: in bf16 plans they become ONE launch (odamd_conv_mp_forward) where the library has the fused
+        form for their shapes (decided in _build, which falls back to two launches otherwise)."""
+        if not FUSE_MP or self.b.dtype != BF16:
+            return ops
+        out, i = [], 0
+        while i < len(ops):
+            a = ops[i]
+            b = ops[i + 1] if i + 1 < len(ops) else None
+            if (b is not None and a['kind'] == 'conv' and b['kind'] == 'conv' and a['x'] is b['x'] and 'mods' not in a
+                    and 'mods' not in b and a['k'] == 1 and b['k'] == 1 and a['s'] == 1 and b['s'] == 1 and a['pool']
+                    and not b['pool'] and len(a['y'].segments) == 1 and len(b['y'].segments) == 1
+                    and a['y'].c == a['y'].cphys and b['y'].c == b['y'].cphys):
+                out.append(dict(kind='mp2', pooled=a, plain=b))
+                i += 2
+            else:
+                out.append(a)
+                i += 1
+        return out
 
     def _fuse_first_two(self, ops):
         """cbs0 (3 -> 16, stride 1) followed by cbs1 (16 -> 32, 3x3 stride 2) in bf16 becomes ONE launch
@@ -315,49 +344,71 @@ class Plan:
         self.weight_version = ver
 
     # ---- lowering ---------------------------------------------------------------------------
+    def _conv_launch(self, op, allow_packed=True):
+        """Descriptor, parameter buffers and profiling record of one conv / head op."""
+        b, dev, dt = self.b, self.b.device, _TORCH_DT[self.b.dtype]
+        B, kind = b.batch, op['kind']
+        m, x = op['mod'], op['x']
+        conv = m.output if kind == 'head' else m.conv
+        cout, k = sum(q.conv.out_channels for q in op['mods']) if 'mods' in op else conv.out_channels, op['k']
+        op['w'] = torch.empty(cout * k * k * x.cphys, dtype=dt, device=dev)
+        op['shift'] = torch.empty(cout, dtype=torch.float32, device=dev)
+        op['scale'] = None if kind == 'head' else torch.empty(cout, dtype=torch.float32, device=dev)
+        d = _lib.ConvDesc()
+        d.x, d.w = self._ptr(x), op['w'].data_ptr()
+        d.scale = op['scale'].data_ptr() if op['scale'] is not None else None
+        d.shift = op['shift'].data_ptr()
+        d.batch, d.h, d.w_in, d.cin, d.cout = B, x.h, x.w, x.cphys, cout
+        d.x_ld, d.ksize, d.stride, d.act = self._ld(x), k, op['s'], op['act']
+        d.dtype, d.in_pool2 = b.dtype, int(op['pool'])
+        if kind == 'head':
+            out = torch.empty((B, cout, x.h, x.w), dtype=torch.float32, device=dev)
+            op['out'] = out
+            d.y, d.y_ld, d.out_nchw_f32 = out.data_ptr(), 0, 1
+        else:
+            d.y, d.y_ld, d.out_nchw_f32 = self._ptr(op['y']), self._ld(op['y']), 0
+            # several layer classes want the weights in the order the kernel's matrix fragments are read
+            g, cb = C.c_int(0), C.c_int(0)
+            if allow_packed and lib.odamd_conv_weight_layout(C.byref(d), C.byref(g), C.byref(cb)):
+                op['frag'] = (g.value, cb.value)
+                per = 32 * g.value
+                op['w'] = torch.empty((cout + per - 1) // per * per * k * k * x.cphys, dtype=dt, device=dev)
+                d.w, d.w_packed = op['w'].data_ptr(), 1
+        self.keep.append(d)
+        ho = (d.h // (2 if op['pool'] else 1) + 2 * ((k - 1) // 2) - k) // op['s'] + 1
+        wo = (d.w_in // (2 if op['pool'] else 1) + 2 * ((k - 1) // 2) - k) // op['s'] + 1
+        cin = conv.in_channels
+        meta = dict(
+            kernel='conv%dx%d_s%d_%s' % (k, k, op['s'], 'c32' if cout <= 32 else 'c64' if cout <= 64 else 'c128'),
+            flops=2.0 * B * ho * wo * cout * k * k * cin,
+            bytes=float(B * x.h * x.w * cin * self.es + B * ho * wo * cout * (4 if kind == 'head' else self.es)
+                        + cout * k * k * cin * self.es),
+            shape='%dx%d %d->%d' % (x.h, x.w, cin, cout))
+        return d, meta
+
     def _build(self):
         b, dev, dt = self.b, self.b.device, _TORCH_DT[self.b.dtype]
         B = b.batch
         for op in b.ops:
             kind = op['kind']
             if kind in ('conv', 'head'):
-                m, x = op['mod'], op['x']
-                conv = m.output if kind == 'head' else m.conv
-                cout, k = sum(q.conv.out_channels for q in op['mods']) if 'mods' in op else conv.out_channels, op['k']
-                op['w'] = torch.empty(cout * k * k * x.cphys, dtype=dt, device=dev)
-                op['shift'] = torch.empty(cout, dtype=torch.float32, device=dev)
-                op['scale'] = None if kind == 'head' else torch.empty(cout, dtype=torch.float32, device=dev)
-                d = _lib.ConvDesc()
-                d.x, d.w = self._ptr(x), op['w'].data_ptr()
-                d.scale = op['scale'].data_ptr() if op['scale'] is not None else None
-                d.shift = op['shift'].data_ptr()
-                d.batch, d.h, d.w_in, d.cin, d.cout = B, x.h, x.w, x.cphys, cout
-                d.x_ld, d.ksize, d.stride, d.act = self._ld(x), k, op['s'], op['act']
-                d.dtype, d.in_pool2 = b.dtype, int(op['pool'])
-                if kind == 'head':
-                    out = torch.empty((B, cout, x.h, x.w), dtype=torch.float32, device=dev)
-                    op['out'] = out
-                    d.y, d.y_ld, d.out_nchw_f32 = out.data_ptr(), 0, 1
-                else:
-                    d.y, d.y_ld, d.out_nchw_f32 = self._ptr(op['y']), self._ld(op['y']), 0
-                    # deep small-map layers: the library wants the weights in fragment order
-                    g, cb = C.c_int(0), C.c_int(0)
-                    if lib.odamd_conv_weight_layout(C.byref(d), C.byref(g), C.byref(cb)):
-                        op['frag'] = (g.value, cb.value)
-                        per = 32 * g.value
-                        op['w'] = torch.empty((cout + per - 1) // per * per * k * k * x.cphys, dtype=dt, device=dev)
-                        d.w, d.w_packed = op['w'].data_ptr(), 1
-                self.keep.append(d)
+                d, meta = self._conv_launch(op)
                 self.launches.append((lib.odamd_conv_forward, [C.byref(d)], 'conv', None))
-                ho = (d.h // (2 if op['pool'] else 1) + 2 * ((k - 1) // 2) - k) // op['s'] + 1
-                wo = (d.w_in // (2 if op['pool'] else 1) + 2 * ((k - 1) // 2) - k) // op['s'] + 1
-                cin = conv.in_channels
-                self.meta[len(self.launches) - 1] = dict(
-                    kernel='conv%dx%d_s%d_%s' % (k, k, op['s'], 'c32' if cout <= 32 else 'c64' if cout <= 64 else 'c128'),
-                    flops=2.0 * B * ho * wo * cout * k * k * cin,
-                    bytes=float(B * x.h * x.w * cin * self.es + B * ho * wo * cout * (4 if kind == 'head' else self.es)
-                                + cout * k * k * cin * self.es),
-                    shape='%dx%d %d->%d' % (x.h, x.w, cin, cout))
+                self.meta[len(self.launches) - 1] = meta
+            elif kind == 'mp2':
+                da, ma = self._conv_launch(op['pooled'], allow_packed=False)
+                db, mb = self._conv_launch(op['plain'], allow_packed=False)
+                if lib.odamd_conv_mp_supported(C.byref(da), C.byref(db)):
+                    self.launches.append((lib.odamd_conv_mp_forward, [C.byref(da), C.byref(db)], 'conv_mp', None))
+                    x = op['plain']['x']
+                    self.meta[len(self.launches) - 1] = dict(      # the input counts once: that is the point of the fusion
+                        kernel='mp_1x1_pair', flops=ma['flops'] + mb['flops'],
+                        bytes=ma['bytes'] + mb['bytes'] - float(B * x.h * x.w * op['plain']['mod'].conv.in_channels * self.es),
+                        shape=mb['shape'] + '+' + ma['shape'].split(' ')[1] + ' pooled')
+                else:
+                    for d, meta in ((da, ma), (db, mb)):
+                        self.launches.append((lib.odamd_conv_forward, [C.byref(d)], 'conv', None))
+                        self.meta[len(self.launches) - 1] = meta
             elif kind == 'first':
                 m, y = op['mod'], op['y']
                 cout = m.conv.out_channels

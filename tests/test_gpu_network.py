@@ -82,6 +82,12 @@ BLOCK_CASES = [
     ('elan', dict(in_=32, out_=64, n=2), (1, 32, 16, 16)),
     ('elan_h', dict(in_=64, out_=32), (2, 64, 8, 8)),
     ('mp', dict(in_=32, out_=64), (2, 32, 16, 16)),
+    # whole 8 x 16 patches, 32 / 64 / 128 input channels: both 1x1 convolutions of the block in one launch (bf16 plans);
+    # the last shape has no whole patches and takes the two separate launches
+    ('mp', dict(in_=128, out_=128), (2, 128, 40, 48)),
+    ('mp', dict(in_=64, out_=128), (3, 64, 24, 32)),
+    ('mp', dict(in_=128, out_=256), (2, 128, 16, 32)),
+    ('mp', dict(in_=32, out_=64), (1, 32, 20, 20)),
     ('sppcspc', dict(in_=64, out_=32), (2, 64, 20, 20)),      # plane fits LDS: cascaded 5x5 pools
     ('sppcspc', dict(in_=32, out_=32), (1, 32, 48, 48)),      # larger plane: direct 13x13 walk
 ]
@@ -105,6 +111,30 @@ def test_block_forward(od, kind, kw, shape, dtype):
         assert_elementwise(got, ref, TOL[dtype])
     finally:
         engine.set_compute_dtype(None)
+
+
+@pytest.mark.parametrize('in_,out_,shape', [(128, 128, (3, 128, 32, 48)), (64, 128, (2, 64, 16, 16)), (128, 256, (1, 128, 24, 32))])
+def test_fused_mp_pair_equals_separate_launches(od, in_, out_, shape):
+    """odamd_conv_mp_forward (both 1x1 convolutions of an mp block in one launch) against the two odamd_conv_forward
+    launches it replaces, on the same weights and input: bit for bit."""
+    engine, layer, _ = od
+    x = torch.from_numpy(np.random.default_rng(7).standard_normal(shape).astype(np.float32)).cuda()
+    outs = []
+    engine.set_compute_dtype('bf16')
+    try:
+        for fuse in (True, False):
+            engine.FUSE_MP = fuse
+            mod = layer.mp(in_, out_)
+            patterns.fill_state_dict(mod)
+            mod = mod.cuda().eval()
+            outs.append(mod(x).cpu().numpy())
+            plans = engine.module_plans(mod)
+            kinds = [name for plan in plans.values() for _, _, name, _ in plan.launches]
+            assert ('conv_mp' in kinds) == fuse, kinds
+    finally:
+        engine.FUSE_MP = True
+        engine.set_compute_dtype(None)
+    assert np.array_equal(outs[0], outs[1])
 
 
 def test_block_golden_f32(od, golden):
