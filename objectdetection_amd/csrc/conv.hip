@@ -1380,35 +1380,71 @@ int launch_stream(const ConvP& c, hipStream_t st) {
 }
 
 // ---- LDS-DMA kernel: configuration, launch -------------------------------------------------------
-struct DmaConfig { int ks, pg, cg, wp, wc, ckb, nbuf; };
+struct DmaConfig { int ks, pg, cg, wp, wc, ckb, nbuf, st; };
 #ifdef ODAMD_LAB
 static int g_lab_no_s3 = 0;
+static int g_lab_no_dma_s2 = 0;
 struct S3Config;
 DmaConfig g_lab_force = {};      // tools/micro/conv_lab.hip tries instantiations through this
 #endif
 
 // Which conv_dma_kernel instantiation serves a layer (bf16, stride 1, plain NHWC in / out), or pg == 0.
+// Output tile and patch of a stride-2 3x3 layer for the LDS-DMA kernel: TH x TW <= 32 * pg output pixels, patch rows of
+// [TW + 1 even][TW + 1 odd] column slots.  Picks the shape that stages the fewest slots overall; ok = false when
+// none fits `max_slots` slots per 16-byte part plane.
+struct S2Tile { int th, tw, ih, iw, iwh, slots; bool ok; };
+S2Tile choose_tile_s2(int Ho, int Wo, int pg, int max_slots) {
+    const int cand[] = {Wo, 64, 40, 32, 20, 16, 10, 8};
+    S2Tile best = {0, 0, 0, 0, 0, 0, false};
+    double best_cost = 1e30;
+    for (int tw : cand) {
+        if (tw > Wo || tw > 32 * pg || tw < 1) continue;
+        for (int th = std::min(Ho, 32 * pg / tw); th >= 1; --th) {
+            const int ih = 2 * (th - 1) + 3, iwh = tw + 1, slots = ih * 2 * iwh;
+            if (slots > max_slots) continue;
+            const double tiles = (double)((Wo + tw - 1) / tw) * ((Ho + th - 1) / th);
+            const double cost = tiles * (slots + 0.5 * 32 * pg);      // staged slots + a share for idle lanes
+            if (cost < best_cost) { best_cost = cost; best = {th, tw, ih, 2 * (tw - 1) + 3, iwh, slots, true}; }
+            break;
+        }
+    }
+    return best;
+}
+
 DmaConfig dma_config(const ConvP& p, int ks, int stride, int dtype) {
     DmaConfig none = {};
-    if (dtype != ODAMD_DTYPE_BF16 || stride != 1 || p.pool || p.upz || p.nchw || p.accum) return none;
+    if (dtype != ODAMD_DTYPE_BF16 || p.pool || p.upz || p.nchw || p.accum) return none;
+    if (stride == 2) {
+#ifdef ODAMD_LAB
+        if (g_lab_force.pg) return g_lab_force.ks == ks && g_lab_force.st == 2 ? g_lab_force : none;
+        if (g_lab_no_dma_s2) return none;
+#endif
+        // mp.cbs3 (model/layer.py:143): 3x3 stride 2 with 64 .. 256 channels on <= 160 x 160 inputs
+        if (ks != 3 || p.Cin < 64 || p.Cin % 16 || p.Cout < 64 || p.H * p.W > 160 * 160) return none;
+        if (!choose_tile_s2(p.Ho, p.Wo, 4, dma_max_in_pix(3, 4, 2)).ok) return none;
+        // measured at batch 64 (tools/micro/conv_lab.hip): 128 output channels per workgroup from 128 channels up
+        if (p.Cout >= 128) return {3, 4, 4, 2, 2, 32, 2, 2};
+        return {3, 4, 2, 4, 1, 32, 2, 2};
+    }
+    if (stride != 1) return none;
     const long long npix = (long long)p.B * p.H * p.W;
 #ifdef ODAMD_LAB
-    if (g_lab_force.pg) return g_lab_force.ks == ks ? g_lab_force : none;
+    if (g_lab_force.pg) return g_lab_force.ks == ks && g_lab_force.st != 2 ? g_lab_force : none;
 #endif
     // measured against conv_igemm_kernel / conv1x1_stream_kernel at batch 64 (tools/micro/conv_lab.hip): the DMA
     // kernel wins where K = taps * cin is deep and the map is small (weights dominate the staged bytes)
     if (ks == 3) {
         if (p.Cin < 64 || p.Cout < 64 || p.H * p.W > 80 * 80) return none;
-        return {3, 8, 2, 4, 1, 32, 2};
+        return {3, 8, 2, 4, 1, 32, 2, 1};
     }
     if (ks == 1) {
         if (p.Cin % 32 || p.Cin < 256 || p.Cout < 128 || npix > 64ll * 40 * 40) return none;
-        return {1, 4, 4, 2, 2, 64, 3};
+        return {1, 4, 4, 2, 2, 64, 3, 1};
     }
     return none;
 }
 
-template <int KS, int PG, int CG, int WP, int WC, int CKB, int NBUF>
+template <int KS, int PG, int CG, int WP, int WC, int CKB, int NBUF, int ST = 1>
 int launch_dma(const ConvP& c, hipStream_t st) {
     constexpr int PARTS = CKB / 16, KSTEPS = CKB / 32, TAPS = KS * KS, NW = WP * WC;
     constexpr size_t W_BYTES = (size_t)CG * TAPS * KSTEPS * 1024;
@@ -1416,9 +1452,16 @@ int launch_dma(const ConvP& c, hipStream_t st) {
     DmaP p = {};
     p.x = c.x; p.w = c.w; p.scale = c.scale; p.shift = c.shift; p.y = c.y;
     p.Cin = c.Cin; p.Cout = c.Cout; p.x_ld = c.x_ld; p.y_ld = c.y_ld; p.act = c.act;
+    p.Ho = c.Ho; p.Wo = c.Wo;
     if (KS == 1) {            // no spatial structure: the batch is one row of pixels
         p.B = 1; p.H = 1; p.W = c.B * c.H * c.W;
+        p.Ho = 1; p.Wo = p.W;
         p.TH = 1; p.TW = 32 * PG; p.IH = 1; p.IW = p.TW;
+    } else if (ST == 2) {
+        p.B = c.B; p.H = c.H; p.W = c.W;
+        const S2Tile t = choose_tile_s2(c.Ho, c.Wo, PG, dma_max_in_pix(KS, PG, 2));
+        if (!t.ok) return ODAMD_E_SHAPE;
+        p.TH = t.th; p.TW = t.tw; p.IH = t.ih; p.IW = t.iw; p.IWH = t.iwh;
     } else {
         p.B = c.B; p.H = c.H; p.W = c.W;
         // per buffer: PARTS * npad * 16 + W_BYTES; the chooser sees bytes per staged pixel and the rest
@@ -1428,15 +1471,16 @@ int launch_dma(const ConvP& c, hipStream_t st) {
         if (!t.ok) return ODAMD_E_SHAPE;
         p.TH = t.th; p.TW = t.tw; p.IH = t.ih; p.IW = t.iw;
     }
-    p.npad = (p.IH * p.IW + 63) & ~63;
-    p.inv_tw = 1.0f / (float)p.TW; p.inv_iw = 1.0f / (float)p.IW;
-    p.tiles_x = (p.W + p.TW - 1) / p.TW;
-    p.tiles_y = (p.H + p.TH - 1) / p.TH;
+    p.IWP = ST == 2 ? 2 * p.IWH : p.IW;
+    p.npad = (p.IH * p.IWP + 63) & ~63;
+    p.inv_tw = 1.0f / (float)p.TW; p.inv_iw = 1.0f / (float)p.IWP;
+    p.tiles_x = (p.Wo + p.TW - 1) / p.TW;
+    p.tiles_y = (p.Ho + p.TH - 1) / p.TH;
     p.ncb = (p.Cout + 32 * CG - 1) / (32 * CG);
     p.nchunk = p.Cin * 2 / CKB;
     p.nblocks = p.B * p.tiles_x * p.tiles_y * p.ncb;
     {
-        const size_t npix = (size_t)p.B * p.H * p.W;
+        const size_t npix = (size_t)p.B * p.Ho * p.Wo;
         p.fast_epi = fast_epilogue_ok(npix, p.y_ld, 2, p.Cout, 32 * (CG / WC), 0);
         p.ybytes = p.fast_epi ? (unsigned)((npix - 1) * p.y_ld * 2 + (size_t)p.Cout * 2) : 0u;
     }
@@ -1447,7 +1491,8 @@ int launch_dma(const ConvP& c, hipStream_t st) {
     const size_t epi = (size_t)NW * 32 * ((CG / WC) * 128 + 16);
     if (lds < epi) lds = epi;
     if (lds > LDS_MAX) return ODAMD_E_SHAPE;
-    auto k = conv_dma_kernel<KS, PG, CG, WP, WC, CKB, NBUF>;
+    if (p.npad > ((dma_max_in_pix(KS, PG, ST) + 63) & ~63)) return ODAMD_E_SHAPE;
+    auto k = conv_dma_kernel<KS, PG, CG, WP, WC, CKB, NBUF, ST>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     k<<<p.nblocks, 64 * NW, lds, st>>>(p);
     return (int)hipGetLastError();
@@ -1455,14 +1500,23 @@ int launch_dma(const ConvP& c, hipStream_t st) {
 
 int dispatch_dma(const ConvP& p, const DmaConfig& g, hipStream_t st) {
 #define ODAMD_DMA_CASE(KS, PG, CG, WP, WC, CKB, NBUF)                                                          \
-    if (g.ks == KS && g.pg == PG && g.cg == CG && g.wp == WP && g.wc == WC && g.ckb == CKB && g.nbuf == NBUF)  \
+    if (g.st != 2 && g.ks == KS && g.pg == PG && g.cg == CG && g.wp == WP && g.wc == WC && g.ckb == CKB && g.nbuf == NBUF)  \
         return launch_dma<KS, PG, CG, WP, WC, CKB, NBUF>(p, st);
+#define ODAMD_DMA_S2_CASE(PG, CG, WP, WC, CKB, NBUF)                                                           \
+    if (g.st == 2 && g.ks == 3 && g.pg == PG && g.cg == CG && g.wp == WP && g.wc == WC && g.ckb == CKB && g.nbuf == NBUF)  \
+        return launch_dma<3, PG, CG, WP, WC, CKB, NBUF, 2>(p, st);
     ODAMD_DMA_CASE(3, 8, 2, 4, 1, 32, 2)
     ODAMD_DMA_CASE(1, 4, 4, 2, 2, 64, 3)
+    ODAMD_DMA_S2_CASE(4, 2, 4, 1, 32, 2)
+    ODAMD_DMA_S2_CASE(4, 4, 2, 2, 32, 2)
+#ifdef LAB_DMA_S2_VARIANTS
+    LAB_DMA_S2_VARIANTS
+#endif
 #ifdef LAB_DMA_VARIANTS
     LAB_DMA_VARIANTS
 #endif
 #undef ODAMD_DMA_CASE
+#undef ODAMD_DMA_S2_CASE
     return ODAMD_E_ARG;
 }
 

@@ -1,4 +1,4 @@
-// LDS-DMA convolution (bf16, stride 1, 1x1 / 3x3, NHWC in and out) for the deep, small-map layers.
+// LDS-DMA convolution (bf16, 1x1 / 3x3 stride 1, 3x3 stride 2, NHWC in and out) for the deep, small-map layers.
 // Included by conv.hip inside its anonymous namespace.
 //
 // Same GEMM view as conv_igemm_kernel (D[cout][pixel], A = weights, B = pixels, one
@@ -15,6 +15,8 @@
 //     consecutive patch pixels of one part (its per-lane source address does the gather, pixels outside
 //     the image read a zero line), and a B-fragment read touches consecutive 16-byte slots.
 // A 1x1 convolution has no spatial structure: the host passes the whole batch as one 1 x (B*H*W) image.
+// Stride 2 keeps the even and the odd columns of a patch row apart ([IWH even][IWH odd] slots per row), so that the
+// 32 consecutive output pixels of a B fragment still read consecutive slots for every tap.
 
 #ifdef ODAMD_LAB_STAMPS
 __device__ unsigned long long g_lab_stamps[1024 * 8 * 16];
@@ -26,6 +28,9 @@ __device__ unsigned long long g_lab_stamps[1024 * 8 * 16];
 struct DmaP {
     const char* x; const char* w; const float* scale; const float* shift; char* y;
     int B, H, W, Cin, Cout, x_ld, y_ld;
+    int Ho, Wo;   // output size (= H, W for stride 1)
+    int IWP;      // slots per patch row: IW, or 2 * IWH for stride 2
+    int IWH;      // stride 2: even columns of a patch row (the odd ones follow)
     int TH, TW, tiles_x, tiles_y, ncb, IH, IW;
     int npad;     // staged pixels per part plane: IH * IW rounded up to 64
     int nchunk, act, nblocks;
@@ -60,15 +65,17 @@ __device__ __forceinline__ void wait_vmcnt_imm() {
 }
 
 // upper bound of staged input pixels per workgroup (the host tile chooser enforces it)
-__host__ __device__ constexpr int dma_max_in_pix(int ks, int pg) { return ks == 1 ? 32 * pg : (pg >= 8 ? 384 : 256); }
+__host__ __device__ constexpr int dma_max_in_pix(int ks, int pg, int st = 1) {
+    return ks == 1 ? 32 * pg : st == 2 ? (pg >= 8 ? 1280 : 704) : (pg >= 8 ? 384 : 256);
+}
 
-template <int KS, int PG, int CG, int WP, int WC, int CKB, int NBUF>
+template <int KS, int PG, int CG, int WP, int WC, int CKB, int NBUF, int ST = 1>
 __global__ void __launch_bounds__(64 * WP * WC) conv_dma_kernel(DmaP p) {
     constexpr int DT = ODAMD_DTYPE_BF16;
     constexpr int TAPS = KS * KS, NW = WP * WC, PGW = PG / WP, CGW = CG / WC;
     constexpr int PARTS = CKB / 16, KSTEPS = CKB / 32;
     constexpr int W_PIECES = CG * TAPS * KSTEPS;                     // 1 KiB each
-    constexpr int MAX_NPJ = (dma_max_in_pix(KS, PG) + 63) / 64;
+    constexpr int MAX_NPJ = (dma_max_in_pix(KS, PG, ST) + 63) / 64;
     constexpr int MAXJ = (PARTS * MAX_NPJ + NW - 1) / NW;            // input pieces per wave and chunk
     constexpr int MAXW = (W_PIECES + NW - 1) / NW;                   // weight pieces per wave and chunk
     constexpr int PAD = (KS - 1) / 2;
@@ -94,8 +101,8 @@ __global__ void __launch_bounds__(64 * WP * WC) conv_dma_kernel(DmaP p) {
     LAB_STAMP(0);
 
     // ---- this wave's share of a chunk's DMA pieces ------------------------------------------------
-    const int n_in = PARTS * ((p.IH * p.IW + 63) >> 6);
-    const int iy0 = oy0 - PAD, ix0 = ox0 - PAD;
+    const int n_in = PARTS * ((p.IH * p.IWP + 63) >> 6);
+    const int iy0 = oy0 * ST - PAD, ix0 = ox0 * ST - PAD;
     int goff[MAXJ];            // byte offset of this lane's source pixel within the image, -1: zero line
     int loff[MAXJ];            // LDS offset of the piece within a buffer (wave uniform)
     int n_mine = 0;
@@ -104,9 +111,11 @@ __global__ void __launch_bounds__(64 * WP * WC) conv_dma_kernel(DmaP p) {
         const int i = wave + jj * NW;
         const int j = i / PARTS, part = i - j * PARTS;
         const int q = 64 * j + lane;
-        const int iy = div_small(q, p.inv_iw), ix = q - iy * p.IW;
+        const int iy = div_small(q, p.inv_iw);
+        int ix = q - iy * p.IWP;
+        if (ST == 2) ix = ix < p.IWH ? 2 * ix : 2 * (ix - p.IWH) + 1;     // slot -> patch column
         const int gy = iy0 + iy, gx = ix0 + ix;
-        const bool inside = i < n_in && iy < p.IH && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const bool inside = i < n_in && iy < p.IH && ix < p.IW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         goff[jj] = inside ? (gy * p.W + gx) * p.x_ld * 2 + part * 16 : -1;
         loff[jj] = (part * p.npad + 64 * j) * 16;
         n_mine += i < n_in;
@@ -149,9 +158,9 @@ __global__ void __launch_bounds__(64 * WP * WC) conv_dma_kernel(DmaP p) {
         const int q = (wp * PGW + i) * 32 + r;
         int ty = div_small(q, p.inv_tw), tx = q - ty * p.TW;
         const int oy = oy0 + ty, ox = ox0 + tx;
-        opix[i] = (ty < p.TH && oy < p.H && ox < p.W) ? oy * p.W + ox : -1;
+        opix[i] = (ty < p.TH && oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
         if (ty >= p.TH) { ty = 0; tx = 0; }
-        b_off[i] = ((ty * p.IW + tx) + h * p.npad) * 16;
+        b_off[i] = ((ty * ST * p.IWP + tx) + h * p.npad) * 16;
     }
     const int a_off = in_bytes + wc * CGW * TAPS * KSTEPS * 1024 + lane * 16;
 
@@ -186,7 +195,8 @@ __global__ void __launch_bounds__(64 * WP * WC) conv_dma_kernel(DmaP p) {
         u32x4 a[2][CGW], bb[2][PGW];
         auto read_group = [&](int g, int slot) {
             const int tap = g / KSTEPS, s = g % KSTEPS;
-            const int tap_off = ((tap / KS) * p.IW + (tap % KS)) * 16;
+            const int tap_off = ST == 2 ? ((tap / KS) * p.IWP + ((tap % KS) & 1) * p.IWH + ((tap % KS) >> 1)) * 16
+                                        : ((tap / KS) * p.IW + (tap % KS)) * 16;
 #pragma unroll
             for (int j = 0; j < CGW; ++j) a[slot][j] = *(const u32x4*)(buf + a_off + ((j * TAPS + tap) * KSTEPS + s) * 1024);
 #pragma unroll
@@ -215,11 +225,11 @@ __global__ void __launch_bounds__(64 * WP * WC) conv_dma_kernel(DmaP p) {
     const int cw0 = co0 + wc * CGW * 32;
     if (p.fast_epi) {
         if (cw0 < p.Cout) {
-            if (p.act) nhwc_epilogue_fast<DT, PGW, CGW, true>(acc, opix, stage, lane, cw0, b * p.H * p.W, aff, p.y, p.ybytes, p.y_ld);
-            else nhwc_epilogue_fast<DT, PGW, CGW, false>(acc, opix, stage, lane, cw0, b * p.H * p.W, aff, p.y, p.ybytes, p.y_ld);
+            if (p.act) nhwc_epilogue_fast<DT, PGW, CGW, true>(acc, opix, stage, lane, cw0, b * p.Ho * p.Wo, aff, p.y, p.ybytes, p.y_ld);
+            else nhwc_epilogue_fast<DT, PGW, CGW, false>(acc, opix, stage, lane, cw0, b * p.Ho * p.Wo, aff, p.y, p.ybytes, p.y_ld);
         }
     } else {
-        nhwc_epilogue<DT, PGW, CGW>(acc, opix, stage, lane, cw0, (size_t)b * p.H * p.W, aff, p.Cout, p.y, p.y_ld, p.act, 0);
+        nhwc_epilogue<DT, PGW, CGW>(acc, opix, stage, lane, cw0, (size_t)b * p.Ho * p.Wo, aff, p.Cout, p.y, p.y_ld, p.act, 0);
     }
     LAB_STAMP(10);
 }

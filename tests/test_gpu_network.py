@@ -56,6 +56,13 @@ BLOCK_CASES = [
     ('cbs', dict(in_=512, out_=256, kernel_size=1, stride=1), (4, 512, 20, 20)),
     ('cbs', dict(in_=256, out_=136, kernel_size=1, stride=1), (3, 256, 19, 21)),
     ('cbs', dict(in_=1024, out_=256, kernel_size=1, stride=1), (2, 1024, 20, 20)),
+    # 3x3 stride 2 with >= 64 channels on maps up to 160 x 160 (mp.cbs3): the LDS-DMA kernel with its even / odd column
+    # planes; ragged tiles, odd output sizes, one and two channel blocks, a ragged channel block
+    ('cbs', dict(in_=64, out_=64, kernel_size=3, stride=2), (2, 64, 80, 80)),
+    ('cbs', dict(in_=128, out_=128, kernel_size=3, stride=2), (3, 128, 40, 40)),
+    ('cbs', dict(in_=256, out_=256, kernel_size=3, stride=2), (1, 256, 40, 40)),
+    ('cbs', dict(in_=64, out_=96, kernel_size=3, stride=2), (2, 64, 37, 53)),
+    ('cbs', dict(in_=80, out_=200, kernel_size=3, stride=2), (1, 80, 26, 30)),
     # 256 / 512 / 1024 input channels, output channels in multiples of 128, pixel count a multiple of 64: the persistent
     # 1x1 kernel with register-resident weights (1..3 channel blocks, one and two channel groups per wave, fewer tiles
     # than workgroups, odd tile counts, several rounds per workgroup)

@@ -11,6 +11,7 @@
 #define LAB_S3_VARIANTS \
     ODAMD_S3_CASE(2, 1, 1, 4, 256, 3) ODAMD_S3_CASE(2, 1, 1, 4, 256, 4) ODAMD_S3_CASE(2, 1, 1, 8, 384, 3) \
     ODAMD_S3_CASE(2, 2, 2, 4, 640, 2)
+#define LAB_DMA_S2_VARIANTS ODAMD_DMA_S2_CASE(8, 2, 4, 1, 32, 2) ODAMD_DMA_S2_CASE(4, 2, 4, 1, 32, 3) ODAMD_DMA_S2_CASE(4, 2, 4, 1, 64, 2) ODAMD_DMA_S2_CASE(4, 2, 2, 2, 32, 2)
 #define LAB_WRES_VARIANTS ODAMD_WRES_CASE(1, 2, 4) ODAMD_WRES_CASE(1, 1, 4) ODAMD_WRES_CASE(1, 2, 2) ODAMD_WRES_CASE(2, 2, 2) ODAMD_WRES_CASE(2, 1, 4) ODAMD_WRES_CASE(2, 1, 2)
 #include "../../objectdetection_amd/csrc/conv.hip"
 
@@ -45,6 +46,8 @@ int main(int argc, char** argv) {
         {"3x3s2 32->64 @320", 320, 32, 64, 3, 2, 0},
         {"1x1 256->128 @80", 80, 256, 128, 1, 1, 0},  {"1x1 512->256 @40", 40, 512, 256, 1, 1, 0},
         {"1x1 256->256 @20", 20, 256, 256, 1, 1, 0},
+        {"3x3s2 64->64 @160", 160, 64, 64, 3, 2, 0},   {"3x3s2 128->128 @80", 80, 128, 128, 3, 2, 0},
+        {"3x3s2 64->64 @80", 80, 64, 64, 3, 2, 0},
     };
     const int only = argc > 1 ? atoi(argv[1]) : -1;
     const int ldmul = argc > 2 ? atoi(argv[2]) : 1;      // x_ld = ldmul * cin, y_ld = ldmul * cout (slices of wider tensors)
@@ -119,12 +122,13 @@ int main(int argc, char** argv) {
             {-4, 1, 0, 0, 0, 0, 0},         // register-resident 1x1 kernel with one channel group per wave
             {-5, 4, 0, 0, 0, 0, 0}, {-5, 2, 0, 0, 0, 0, 0},   // ... with 4 / 2 ring buffers
             {-1, 4, 256, 3, 0, 0, 0}, {-1, 4, 256, 4, 0, 0, 0}, {-1, 8, 384, 3, 0, 0, 0}, {-2, 4, 640, 2, 0, 0, 0},   // conv_s3 variants: pg, npad, nbuf
+            {3, 8, 2, 4, 1, 32, 2, 2}, {3, 4, 2, 4, 1, 32, 3, 2}, {3, 4, 2, 4, 1, 64, 2, 2}, {3, 4, 4, 2, 2, 32, 2, 2}, {3, 4, 2, 2, 2, 32, 2, 2},
             {3, 8, 2, 4, 1, 64, 2}, {3, 8, 2, 4, 1, 32, 3}, {3, 8, 2, 4, 1, 32, 2}, {3, 4, 2, 2, 2, 32, 3}, {3, 4, 2, 4, 1, 32, 3},
             {3, 4, 4, 2, 2, 32, 2}, {3, 8, 4, 4, 2, 32, 2}, {3, 8, 4, 4, 2, 32, 3}, {1, 8, 4, 2, 2, 128, 2}, {1, 4, 4, 2, 2, 128, 2},
             {1, 4, 4, 2, 2, 64, 3}, {1, 4, 4, 2, 2, 64, 2}, {1, 8, 4, 4, 2, 64, 3}, {1, 8, 8, 4, 2, 64, 2}, {1, 8, 4, 4, 2, 128, 2}};
         double best = us;
         for (const DmaConfig& v : variants) {
-            if (v.ks > 0 && (v.ks != c.k || c.s != 1 || c.pool)) continue;
+            if (v.ks > 0 && (v.ks != c.k || c.s != (v.st == 2 ? 2 : 1) || c.pool)) continue;
             if (v.ks > 0 && only < 0) continue;     // the full sweep only with a case selected
             g_lab_s3 = {};
             g_lab_no_wres = 0;
@@ -202,7 +206,7 @@ int main(int argc, char** argv) {
                 printf("\n     ");
             }
 #endif
-            printf(" [%s%d,%d,%d,%d,%d,%d]", v.ks == -3 ? "dma:" : v.ks == -4 ? "wres1:" : v.ks == -5 ? "nbuf:" : "", v.pg, v.cg, v.wp, v.wc, v.ckb, v.nbuf);
+            printf(" [%s%s%d,%d,%d,%d,%d,%d]", v.st == 2 ? "s2:" : "", v.ks == -3 ? "dma:" : v.ks == -4 ? "wres1:" : v.ks == -5 ? "nbuf:" : "", v.pg, v.cg, v.wp, v.wc, v.ckb, v.nbuf);
             if (rc2) printf(" rc=%d", rc2); else printf(" %.1f%s", us2, maxdiff > 0.02 ? "(BAD)" : "");
             if (!rc2 && maxdiff <= 0.02 && us2 < best) best = us2;
         }
