@@ -1181,35 +1181,42 @@ spp_pool3_kernel(const char* __restrict__ x, char* __restrict__ y5, char* __rest
 
 // Same three pools as a cascade for small maps: pool9 = pool5(pool5(x)), pool13 = pool5(pool9) (maxima
 // are exact, so the results are identical), each 5x5 pool as a row pass and a column pass.  One
-// workgroup per (image, 16-byte channel vector) keeps the whole H x W plane in LDS: 30 window reads
-// per output instead of 169.
+// workgroup per (image, VPW consecutive 16-byte channel vectors) keeps the whole H x W plane of its channels in
+// LDS: 30 window reads per output instead of 169, and every global access is a run of 16 VPW contiguous bytes
+// per pixel (a workgroup per single vector touches 16 bytes of every 128-byte line).
+template <int VPW>
 __global__ void __launch_bounds__(256)
 spp_cascade_kernel(const char* __restrict__ x, char* __restrict__ y5, char* __restrict__ y9, char* __restrict__ y13,
-                   int H, int W, int x_ld, int y_ld, int es, int dt) {
+                   int H, int W, int vecs, int x_ld, int y_ld, int es, int dt) {
     extern __shared__ __attribute__((aligned(16))) uint4 plane[];
-    const int hw = H * W, v = blockIdx.x, b = blockIdx.y;
+    const int hw = H * W, v0 = blockIdx.x * VPW, b = blockIdx.y;
+    const int nv = min(VPW, vecs - v0);                 // vectors of this workgroup (the last one may hold fewer)
+    const int n = hw * VPW;                             // items: (pixel, vector) with the vector fastest
     uint4* A = plane;
-    uint4* Bp = plane + hw;
-    for (int p = threadIdx.x; p < hw; p += 256) A[p] = *(const uint4*)(x + (((size_t)b * hw + p) * x_ld) * es + v * 16);
+    uint4* Bp = plane + n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int p = i / VPW, v = i - p * VPW;
+        if (v < nv) A[i] = *(const uint4*)(x + (((size_t)b * hw + p) * x_ld) * es + (v0 + v) * 16);
+    }
     char* outs[3] = {y5, y9, y13};
 #pragma unroll 1
     for (int stage = 0; stage < 3; ++stage) {
         __syncthreads();
-        for (int p = threadIdx.x; p < hw; p += 256) {       // row pass A -> Bp
-            const int py = p / W, px = p - py * W;
-            uint4 m = A[p];
+        for (int i = threadIdx.x; i < n; i += 256) {        // row pass A -> Bp
+            const int p = i / VPW, px = p % W;
+            uint4 m = A[i];
             for (int d = -2; d <= 2; ++d)
-                if (d != 0 && px + d >= 0 && px + d < W) m = vmax16(m, A[p + d], dt);
-            Bp[p] = m;
+                if (d != 0 && px + d >= 0 && px + d < W) m = vmax16(m, A[i + d * VPW], dt);
+            Bp[i] = m;
         }
         __syncthreads();
-        for (int p = threadIdx.x; p < hw; p += 256) {       // column pass Bp -> A, and out
-            const int py = p / W;
-            uint4 m = Bp[p];
+        for (int i = threadIdx.x; i < n; i += 256) {        // column pass Bp -> A, and out
+            const int p = i / VPW, v = i - p * VPW, py = p / W;
+            uint4 m = Bp[i];
             for (int d = -2; d <= 2; ++d)
-                if (d != 0 && py + d >= 0 && py + d < H) m = vmax16(m, Bp[p + d * W], dt);
-            A[p] = m;
-            *(uint4*)(outs[stage] + (((size_t)b * hw + p) * y_ld) * es + v * 16) = m;
+                if (d != 0 && py + d >= 0 && py + d < H) m = vmax16(m, Bp[i + d * W * VPW], dt);
+            A[i] = m;
+            if (v < nv) *(uint4*)(outs[stage] + (((size_t)b * hw + p) * y_ld) * es + (v0 + v) * 16) = m;
         }
     }
 }
@@ -1963,9 +1970,14 @@ int odamd_spp_pool3_forward(const void* x, void* y5, void* y9, void* y13, int ba
     if (!y9 || !y13 || batch < 1 || h < 1 || w < 1) return ODAMD_E_ARG;
     if (((uintptr_t)y9 & 15) || ((uintptr_t)y13 & 15)) return ODAMD_E_ALIGN;
     const int vecs = c * es / 16;
+    if ((size_t)h * w * 32 * 4 <= 64 * 1024 && vecs >= 4) {   // four vectors' planes (twice) fit LDS: 64-byte runs per pixel
+        spp_cascade_kernel<4><<<dim3((vecs + 3) / 4, batch), 256, (size_t)h * w * 32 * 4, (hipStream_t)stream>>>(
+            (const char*)x, (char*)y5, (char*)y9, (char*)y13, h, w, vecs, x_ld, y_ld, es, dtype);
+        return (int)hipGetLastError();
+    }
     if ((size_t)h * w * 32 <= 64 * 1024) {      // the plane (twice) fits LDS: cascade of 5x5 pools
-        spp_cascade_kernel<<<dim3(vecs, batch), 256, (size_t)h * w * 32, (hipStream_t)stream>>>(
-            (const char*)x, (char*)y5, (char*)y9, (char*)y13, h, w, x_ld, y_ld, es, dtype);
+        spp_cascade_kernel<1><<<dim3(vecs, batch), 256, (size_t)h * w * 32, (hipStream_t)stream>>>(
+            (const char*)x, (char*)y5, (char*)y9, (char*)y13, h, w, vecs, x_ld, y_ld, es, dtype);
         return (int)hipGetLastError();
     }
     spp_pool3_kernel<<<grid_for((size_t)batch * h * w * vecs), 256, 0, (hipStream_t)stream>>>(
