@@ -58,32 +58,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int cbase = cb * 128 * CGW;              // first channel of the workgroup
     const int cw0 = cbase + wave * 32 * CGW;       // first channel of the wave
 
-    // ---- weights: the A fragments of every k-step, once -------------------------------------------------
-    u32x4 A[KCH][CGW][KS16];
-    {
-        const char* wb = p.w + ((size_t)(cb * 4 * CGW + wave * CGW) * (KCH * KS16)) * 1024 + lane * 16;
-#pragma unroll
-        for (int j = 0; j < CGW; ++j)
-#pragma unroll
-            for (int ch = 0; ch < KCH; ++ch)
-#pragma unroll
-                for (int s = 0; s < KS16; ++s) A[ch][j][s] = *(const u32x4*)(wb + ((size_t)(j * KCH + ch) * KS16 + s) * 1024);
-        // The weights only ever feed matrix instructions, which read the accumulation half of the register file
-        // directly; the results are post-processed by vector instructions, which cannot.  Steer the allocation
-        // accordingly (otherwise every result is copied out of that half one register at a time).
-#pragma unroll
-        for (int j = 0; j < CGW; ++j)
-#pragma unroll
-            for (int ch = 0; ch < KCH; ++ch)
-#pragma unroll
-                for (int s = 0; s < KS16; ++s) asm volatile("" : "+a"(A[ch][j][s]));
-    }
-    for (int t = tid; t < 128 * CGW; t += 256) {
-        aff[t] = p.scale[cbase + t];
-        aff[128 * CGW + t] = p.shift[cbase + t];
-    }
-    __syncthreads();                               // the affine table is in LDS
-
+    // affine constants of the workgroup's channels: requested first, written to LDS once everything else is on its way
+    float aff_sc = 0.f, aff_sh = 0.f;
+    if (tid < 128 * CGW) { aff_sc = p.scale[cbase + tid]; aff_sh = p.shift[cbase + tid]; }
     // ---- DMA pieces of a unit: piece i = wave + 4 jj covers pixels 8 (i / 4) .. + 7, parts 8 (i % 4) .. + 7 -------
     // (the pixel count is a multiple of 64: every tile that exists is whole)
     const char* psrc[MAXJ];   // this lane's source of piece jj for tile 0, unit 0
@@ -107,9 +84,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // A tile past the end copies the last tile (valid memory); its results are never stored.
     auto unit_offset = [&](const Unit& u) { return (size_t)min(u.tile, p.ntiles - 1) * tile_bytes + u.ch * 512; };
     auto issue_piece = [&](int jj, size_t uoff, char* buf) { dma16(psrc[jj] + uoff, buf + loff[jj]); };
-    // the weights must be in their registers before the first matrix instruction, and the loop's counted waits
-    // only know DMA pieces and stores: drain the weight loads first
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The first units are requested before the weights: a small layer is a few tiles per workgroup, and the weight
+    // loads (128 .. 256 KB per workgroup) would otherwise stand in front of its first tile.
     Unit q[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -117,6 +93,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int jj = 0; jj < MAXJ; ++jj) issue_piece(jj, unit_offset(q[i]), bufs + i * WRES_UNIT);
     }
+    // ---- weights: the A fragments of every k-step, once -------------------------------------------------
+    u32x4 A[KCH][CGW][KS16];
+    {
+        const char* wb = p.w + ((size_t)(cb * 4 * CGW + wave * CGW) * (KCH * KS16)) * 1024 + lane * 16;
+#pragma unroll
+        for (int j = 0; j < CGW; ++j)
+#pragma unroll
+            for (int ch = 0; ch < KCH; ++ch)
+#pragma unroll
+                for (int s = 0; s < KS16; ++s) A[ch][j][s] = *(const u32x4*)(wb + ((size_t)(j * KCH + ch) * KS16 + s) * 1024);
+        // The weights only ever feed matrix instructions, which read the accumulation half of the register file
+        // directly; the results are post-processed by vector instructions, which cannot.  Steer the allocation
+        // accordingly (otherwise every result is copied out of that half one register at a time).
+#pragma unroll
+        for (int j = 0; j < CGW; ++j)
+#pragma unroll
+            for (int ch = 0; ch < KCH; ++ch)
+#pragma unroll
+                for (int s = 0; s < KS16; ++s) asm volatile("" : "+a"(A[ch][j][s]));
+    }
+    // the weights must be in their registers before the first matrix instruction, and the loop's counted waits
+    // only know DMA pieces and stores: drain everything once
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid < 128 * CGW) { aff[tid] = aff_sc; aff[128 * CGW + tid] = aff_sh; }
+    __syncthreads();                               // the affine table is in LDS (and every load above has landed)
 
     // B fragment of (pixel group i, k-step s): part 2 s + h of pixel 32 i + r
     int b_off[PGW];
