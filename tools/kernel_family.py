@@ -18,17 +18,19 @@ def family(name, conv_only=False):
     m = re.search(r'conv1x1_stream_kernel<(\d+), (\d+),', name)
     if m:
         return 'conv1x1_s1_%s' % _CG[int(m.group(2))]
-    m = re.search(r'conv1x1_wres_kernel<(\d+), (\d+),', name)      # <CINB, COUTB, ...>: weights resident, cout >= 128
+    m = re.search(r'conv1x1_wres_kernel<(\d+), (\d+),', name)      # <KCH, CGW, ...>: weights resident in registers, output channels in multiples of 128
     if m:
         return 'conv1x1_s1_c128'
     m = re.search(r'conv_igemm_kernel<(\d+), (\d+), (\d+), (\d+),', name)
     if m:
         _, ks, st, cg = (int(v) for v in m.groups())
         return 'conv%dx%d_s%d_%s' % (ks, ks, st, _CG[cg])
-    m = re.search(r'conv_dma_kernel<(\d+), (\d+), (\d+),', name)
+    m = re.search(r'conv_dma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>', name)
     if m:
-        ks, _, cg = (int(v) for v in m.groups())
-        return 'conv1x1_s1_c128' if ks == 1 else 'conv3x3_s1_dma'
+        ks, st = int(m.group(1)), int(m.group(8))
+        return 'conv1x1_s1_c128' if ks == 1 else 'conv3x3_s%d_dma' % st
+    if 'conv_mp_kernel' in name:
+        return 'mp_1x1_pair'
     m = re.search(r'conv_s3_kernel<(\d+), (\d+), (\d+),', name)
     if m:
         _, cg, st = (int(v) for v in m.groups())
