@@ -263,10 +263,19 @@ class TrainPlan:
         self.bufs = [torch.zeros((B, h, w, c), dtype=self.tdt, device=dev) for c, h, w in pb.buffers]
         total = sum(t.numel() for t in self.bufs)
         self.grad_pool = torch.zeros(total, dtype=self.tdt, device=dev)
-        self.gbufs, o = [], 0
-        for t in self.bufs:
-            self.gbufs.append(self.grad_pool[o:o + t.numel()].view(t.shape))
+        # Gradient buffers whose first writer of the backward pass stores (instead of adding) need no zero fill; the
+        # others come first in the pool and are cleared once per step.
+        self.dgrad_stores, need_zero = self._gradient_write_modes()
+        order = sorted(range(len(self.bufs)), key=lambda i: (i not in need_zero, i))
+        self.gbufs, o = [None] * len(self.bufs), 0
+        for i in order:
+            t = self.bufs[i]
+            self.gbufs[i] = self.grad_pool[o:o + t.numel()].view(t.shape)
             o += t.numel()
+            if i in need_zero:
+                self.grad_zero = self.grad_pool[:o]
+        if not need_zero:
+            self.grad_zero = None
         self.image8 = None if self.block else torch.zeros((B, self.size, self.size, 8), dtype=self.tdt, device=dev)
         maxc = 16
         self.fwd, self.bwd = [], []
@@ -388,6 +397,63 @@ class TrainPlan:
         self.keep.append(d)
         return d
 
+    def _gradient_write_modes(self):
+        """Walks the backward pass symbolically.  Every activation gradient is written by the data-gradient launches of the
+        layers that consumed the activation and by the pool / upsample backward kernels, which add into it.  A convolution's
+        data gradient that is the FIRST writer of its channel range can store; afterwards everything adds.  Returns (ids of
+        the ops whose data gradient stores, buffers that still need a zero fill per step: those where an adding kernel or a
+        reader meets channels nobody stored to)."""
+        written = [[False] * c for c, _, _ in self.pb.buffers]
+        stores, need_zero = set(), set()
+
+        def span(act, off=0, n=None):
+            lo = act.c0 + off
+            return act.buf, lo, lo + (act.cphys if n is None else n)
+
+        def covered(buf, lo, hi):
+            return all(written[buf][lo:hi])
+
+        def mark(buf, lo, hi):
+            written[buf][lo:hi] = [True] * (hi - lo)
+
+        def read(act):
+            buf, lo, hi = span(act)
+            if not covered(buf, lo, hi):
+                need_zero.add(buf)
+
+        def add(act):
+            buf, lo, hi = span(act)
+            if not covered(buf, lo, hi):
+                need_zero.add(buf)
+            mark(buf, lo, hi)
+
+        for op in reversed(self.ops):
+            kind = op['kind']
+            if kind == 'first':
+                read(op['y'])
+            elif kind in ('conv', 'head'):
+                if kind == 'conv':
+                    read(op['y'])
+                buf, lo, hi = span(op['x'])
+                if not any(written[buf][lo:hi]):
+                    stores.add(id(op))
+                elif not covered(buf, lo, hi):
+                    need_zero.add(buf)
+                mark(buf, lo, hi)
+            elif kind in ('maxpool2', 'upsample2'):
+                read(op['y'])
+                add(op['x'])
+            elif kind == 'spp':
+                for y in op['ys']:
+                    read(y)
+                    add(op['x'])
+            elif kind == 'from_nchw':
+                read(op['y'])
+            elif kind == 'to_nchw':
+                for off, n in op['x'].segments:
+                    mark(*span(op['x'], off, n))
+        return stores, need_zero
+
     def _lower_backward(self):
         B, st = self.batch, self.state
         bwd = []
@@ -422,7 +488,8 @@ class TrainPlan:
                                          x.w, n, cout, k, op['s'], self.dtype], 'wgrad', ('columns', m.conv.weight, src, n)))
                             src += n
                     d = self._conv_desc(raw.data_ptr(), op['wb'], None, self._gptr(x), raw.shape[1], raw.shape[2], cphys,
-                                        x.cphys, cphys, self._ld(x), k, 1, upz=int(op['s'] == 2), accum=1)
+                                        x.cphys, cphys, self._ld(x), k, 1, upz=int(op['s'] == 2),
+                                        accum=int(id(op) not in self.dgrad_stores))
                     bwd.append((lib.odamd_conv_forward, [C.byref(d)], 'dgrad', None))
                 bwd.append(('mark', (m.conv.weight, m.bn.weight, m.bn.bias), 'mark', None))
             elif kind == 'head':
@@ -442,7 +509,7 @@ class TrainPlan:
                             [self._aptr(x), self._ld(x), dyb.data_ptr(), cphys, st.grad_ptr(m.output.weight), B, x.h,
                              x.w, x.c, cout, 1, 1, self.dtype], 'wgrad', None))
                 d = self._conv_desc(dyb.data_ptr(), op['wb'], None, self._gptr(x), x.h, x.w, cphys, x.cphys, cphys,
-                                    self._ld(x), 1, 1, accum=1)
+                                    self._ld(x), 1, 1, accum=int(id(op) not in self.dgrad_stores))
                 bwd.append((lib.odamd_conv_forward, [C.byref(d)], 'dgrad', None))
                 bwd.append(('mark', (m.output.weight, m.output.bias), 'mark', None))
             elif kind == 'maxpool2':
@@ -560,7 +627,8 @@ class TrainPlan:
     def backward(self, image, reducer=None):
         """Backward of the last forward from self.dpred; gradients are ADDED to state.grad."""
         stream = _stream()
-        self.grad_pool.zero_()
+        if self.grad_zero is not None:
+            self.grad_zero.zero_()
         if not self.block:
             check(lib.odamd_nchw_to_nhwc(image.data_ptr(), self.image8.data_ptr(), self.batch, 3, self.size, self.size, 3,
                                          8, self.dtype, stream), 'image_to_nhwc')

@@ -27,4 +27,12 @@ for _ in range(n):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
+single = []
+for _ in range(5):                      # one step into an empty queue: the host-side cost alone
+    torch.cuda.synchronize()
+    a0 = time.perf_counter()
+    tc.train_step(image, screen, expend)
+    single.append(1e3 * (time.perf_counter() - a0))
+torch.cuda.synchronize()
+print('amp=%s: enqueue of one step into an empty queue: %s ms' % (amp, ' '.join('%.2f' % v for v in single)))
 print(f'amp={amp}: host enqueue {1e3 * (t1 - t0) / n:.2f} ms per step; with device drain {1e3 * (t2 - t0) / n:.2f} ms per step')
