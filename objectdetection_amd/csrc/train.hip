@@ -463,22 +463,37 @@ upsample2_bwd_kernel(const char* __restrict__ dy, int dy_ld, char* __restrict__ 
 // consecutive channels: conflict free) and accumulates all taps in registers.  The four waves are laid out
 // WCO x WCI over the tile and, when the tile is smaller than four waves, WPX ways over the pixels of
 // a patch.  Each wave keeps R x R MFMA tiles per tap.
-// Every wave stores its sums to its own slice of `part` ([split][pixel group][Cout][Cin][taps], the torch
-// weight layout) and a second kernel folds the slices into dW in a fixed order: no atomics, the
-// result is reproducible.  Workgroup ids are laid out so that the pairs of one split (which read the
+// Every wave stores its sums to its own slice of `part` ([split][pixel group][taps][Cout][Cin]: the lanes of a
+// store are consecutive input channels) and a second kernel folds the slices in a fixed order and adds the sums
+// to dW in the torch weight layout [Cout][Cin][taps]: no atomics, the result is reproducible.  Workgroup ids are laid out so that the pairs of one split (which read the
 // same patches) run on the same XCD and share its L2.
 // ------------------------------------------------------------------------------------------
 struct WgradP {
     const void* x; const void* dy; float* part;
     int B, H, W, Ho, Wo, Cin, Cout, x_ld, dy_ld;
     int TH, TW, npix, tiles_x, tiles_y, IH, IW, nsplit, ntiles, ncin, npairs;
+    float inv_tw, inv_iw;      // 1 / TW, 1 / IW (div_small_t)
     size_t slice;
 };
 
 // The GEMM runs on v_mfma_f32_32x32x16_bf16 (float32 accumulation and float32 dW).  The MFMA wants, per lane, 8 consecutive K (= pixel) values of one channel, while the
-// staged NHWC patches keep channels contiguous: a lane gathers its 8 pixels with eight 16-bit LDS
-// reads (32 consecutive channels per half wave: conflict free), so no transposed copy and no
-// alignment constraint on the tap shifts.  One K step covers 16 pixels of the patch.
+// staged NHWC patches keep channels contiguous: the transposing LDS read ds_read_b64_tr_b16 delivers, to each group
+// of 16 lanes, a block of 4 pixel rows x 16 channels column-major (lane i gets channel i of the four rows), every
+// lane supplying the address of one row piece.  Two such reads make a lane's 8 pixels; the rows are addressed
+// through the pixel table, so tap shifts and patch-row breaks need no alignment.  One K step covers 16 pixels of
+// the patch.  Pixel rows in LDS are padded so that four consecutive rows of 64 bytes fall on different banks
+// (wgrad_row_bytes).
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8_t lds_tr8(const char* first, const char* second) {
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)first);
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)second);
+    return bf16x8_t{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+// LDS bytes per staged pixel of a `channels`-wide tile whose consecutive K pixels are `step` rows apart
+__host__ __device__ constexpr int wgrad_row_bytes(int channels, int step) {
+    return step == 1 ? (channels == 32 ? 64 : channels * 2 + 64) : channels * 2 + 32;
+}
 __device__ __forceinline__ uint4 mask_bf16x8(uint4 v, int valid) {   // keep the first `valid` (1..7) elements
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -500,6 +515,53 @@ __device__ __forceinline__ void split_store(float4 v, uint16_t* hi, uint16_t* lo
     *(uint2*)lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
 }
 
+__device__ __forceinline__ int div_small_t(int v, float inv) { return (int)(((float)v + 0.5f) * inv); }   // exact for v < 2^21, divisor < 2^12
+
+// Stages `total` 16-byte global pieces (PP per pixel row) into LDS rows of `ps` bytes.  where(pixel, part, valid) returns
+// the piece's address and the number of real elements in it (<= 0: none, the piece is zero).  SPLIT: the piece holds
+// four float32 values, staged as (hi, lo) bf16 pairs; otherwise eight bf16 values.
+template <bool SPLIT, int PP, typename F>
+__device__ __forceinline__ void stage_pieces(int tid, int total, int ps, char* hi, char* lo, F&& where) {
+    constexpr int NB = 12, EPP = SPLIT ? 4 : 8;
+    for (int b0 = 0; b0 < total; b0 += 256 * NB) {
+        uint4 v[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int i = b0 + tid + j * 256;
+            v[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < total) {
+                int valid;
+                const char* src = where(i / PP, i % PP, valid);
+                if (valid > 0) {
+                    v[j] = *(const uint4*)src;
+                    if (valid < EPP) {
+                        if constexpr (SPLIT) {
+                            if (valid < 2) v[j].y = 0u;
+                            if (valid < 3) v[j].z = 0u;
+                            v[j].w = 0u;
+                        } else {
+                            v[j] = mask_bf16x8(v[j], valid);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int i = b0 + tid + j * 256;
+            if (i < total) {
+                const int pix = i / PP, part = i % PP;
+                if constexpr (SPLIT) {
+                    const float4 f = make_float4(__uint_as_float(v[j].x), __uint_as_float(v[j].y), __uint_as_float(v[j].z), __uint_as_float(v[j].w));
+                    split_store(f, (uint16_t*)(hi + pix * ps + part * 8), (uint16_t*)(lo + pix * ps + part * 8));
+                } else {
+                    *(uint4*)(hi + pix * ps + part * 16) = v[j];
+                }
+            }
+        }
+    }
+}
+
 // SPLIT: x and dy are float32; every value is staged as two bf16 numbers hi = bf16(v), lo = bf16(v - hi)
 // and a product is taken as hi*hi + hi*lo + lo*hi on three bf16 MFMAs with float32 accumulation (the
 // dropped lo*lo term and the rounding of lo are ~2^-17 of the product): float32-grade weight gradients
@@ -510,33 +572,35 @@ __global__ void __launch_bounds__(256) conv_wgrad_bf16_kernel(WgradP p) {
     constexpr int CO_T = 32 * WCO * R, CI_T = 32 * WCI * R, WPX = 4 / (WCO * WCI);
     constexpr int NACC = TAPS * R * R;
     constexpr int EPP = SPLIT ? 4 : 8;                     // elements per 16-byte piece in global memory
+    constexpr int GES = SPLIT ? 4 : 2;                     // bytes per element in global memory
     constexpr int PCO = CO_T / EPP, PCI = CI_T / EPP;      // pieces per staged pixel
     extern __shared__ __attribute__((aligned(16))) char wl8[];
     const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
     const int pair = slot % p.npairs, split = (slot / p.npairs) * 8 + xcd;
     if (split >= p.nsplit) return;
     const int npix = p.npix, nhalo = p.IH * p.IW;
-    int* tab = (int*)wl8;                                   // [npix] halo element offset of tap (0,0)
-    uint16_t* dyl = (uint16_t*)(wl8 + (size_t)npix * 4);    // [npix][CO_T]   (SPLIT: hi parts)
-    uint16_t* xl = dyl + (size_t)npix * CO_T;               // [IH*IW][CI_T]  (SPLIT: hi parts)
-    uint16_t* dyl_lo = xl + (size_t)nhalo * CI_T;           // SPLIT only: lo parts, same shapes
-    uint16_t* xl_lo = dyl_lo + (size_t)npix * CO_T;
+    constexpr int PSA = wgrad_row_bytes(CO_T, 1), PSX = wgrad_row_bytes(CI_T, ST);   // LDS bytes per dY / x pixel
+    int* tab = (int*)wl8;                                   // [npix] halo byte offset of tap (0,0)
+    char* dyl = wl8 + (size_t)npix * 4;                     // [npix][PSA]    (SPLIT: hi parts)
+    char* xl = dyl + (size_t)npix * PSA;                    // [IH*IW][PSX]   (SPLIT: hi parts)
+    char* dyl_lo = xl + (size_t)nhalo * PSX;                // SPLIT only: lo parts, same shapes
+    char* xl_lo = dyl_lo + (size_t)npix * PSA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, kk = lane >> 5;
+    // transposed reads: lane 4q + p of a 16-lane group addresses row q, channels 4p .. 4p+3 of the group's 16
+    const int trq = (lane >> 2) & 3, trc = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
     const int wco = wave % WCO, wci = (wave / WCO) % WCI, wpx = wave / (WCO * WCI);
     const int cb = pair / p.ncin, ib = pair % p.ncin;
     const int co0 = cb * CO_T, ci0 = ib * CI_T;
     const int nco = min(CO_T, p.Cout - co0), nci = min(CI_T, p.Cin - ci0);
-    const uint16_t* xg = (const uint16_t*)p.x;
-    const uint16_t* dyg = (const uint16_t*)p.dy;
 
     for (int q = tid; q < npix; q += 256) {
-        const int ty = q / p.TW, tx = q - ty * p.TW;
-        tab[q] = ty < p.TH ? ((ty * ST) * p.IW + tx * ST) * CI_T : 0;
+        const int ty = div_small_t(q, p.inv_tw), tx = q - ty * p.TW;
+        tab[q] = ty < p.TH ? ((ty * ST) * p.IW + tx * ST) * PSX : 0;
     }
     int tapoff[TAPS];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) tapoff[t] = ((t / KS) * p.IW + (t % KS)) * CI_T;
+    for (int t = 0; t < TAPS; ++t) tapoff[t] = ((t / KS) * p.IW + (t % KS)) * PSX;
 
     f32x16_t acc[NACC];
 #pragma unroll
@@ -550,76 +614,42 @@ __global__ void __launch_bounds__(256) conv_wgrad_bf16_kernel(WgradP p) {
         const int b = t / (p.tiles_x * p.tiles_y), tt = t % (p.tiles_x * p.tiles_y);
         const int oy0 = (tt / p.tiles_x) * p.TH, ox0 = (tt % p.tiles_x) * p.TW;
         __syncthreads();
-        for (int i = tid; i < npix * PCO; i += 256) {
-            const int pix = i / PCO, part = i % PCO;
-            const int ty = pix / p.TW, tx = pix - ty * p.TW;
-            const int oy = oy0 + ty, ox = ox0 + tx;
-            const bool in = ty < p.TH && oy < p.Ho && ox < p.Wo && part * EPP < nco;
-            if constexpr (SPLIT) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (in) {
-                    const float* sp = (const float*)p.dy + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0 + part * 4;
-                    if (part * 4 + 4 <= nco) v = *(const float4*)sp;
-                    else { v.x = sp[0]; if (part * 4 + 1 < nco) v.y = sp[1]; if (part * 4 + 2 < nco) v.z = sp[2]; }
-                }
-                split_store(v, dyl + pix * CO_T + part * 4, dyl_lo + pix * CO_T + part * 4);
-            } else {
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (in) {
-                    v = *(const uint4*)(dyg + (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0 + part * 8);
-                    if (part * 8 + 8 > nco) v = mask_bf16x8(v, nco - part * 8);
-                }
-                *(uint4*)(dyl + pix * CO_T + part * 8) = v;
-            }
-        }
+        // Staging in batches: the global loads of up to NB pieces per thread are all in flight before the first LDS
+        // store (one memory round trip per batch instead of one per piece).
         const int iy0 = oy0 * ST - PAD, ix0 = ox0 * ST - PAD;
-        for (int i = tid; i < nhalo * PCI; i += 256) {
-            const int pix = i / PCI, part = i % PCI;
-            const int hy = pix / p.IW;
+        const char* dyb = (const char*)p.dy + ((size_t)b * p.Ho * p.Wo) * p.dy_ld * GES;
+        const char* xbp = (const char*)p.x + ((size_t)b * p.H * p.W) * p.x_ld * GES;
+        stage_pieces<SPLIT, PCO>(tid, npix * PCO, PSA, dyl, dyl_lo, [&](int pix, int part, int& valid) -> const char* {
+            const int ty = div_small_t(pix, p.inv_tw), tx = pix - ty * p.TW;
+            const int oy = oy0 + ty, ox = ox0 + tx;
+            valid = (ty < p.TH && oy < p.Ho && ox < p.Wo) ? nco - part * EPP : 0;
+            return dyb + ((size_t)(oy * p.Wo + ox) * p.dy_ld + co0 + part * EPP) * GES;
+        });
+        stage_pieces<SPLIT, PCI>(tid, nhalo * PCI, PSX, xl, xl_lo, [&](int pix, int part, int& valid) -> const char* {
+            const int hy = div_small_t(pix, p.inv_iw);
             const int gy = iy0 + hy, gx = ix0 + pix - hy * p.IW;
-            const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && part * EPP < nci;
-            if constexpr (SPLIT) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (in) {
-                    const float* sp = (const float*)p.x + (((size_t)b * p.H + gy) * p.W + gx) * p.x_ld + ci0 + part * 4;
-                    if (part * 4 + 4 <= nci) v = *(const float4*)sp;
-                    else { v.x = sp[0]; if (part * 4 + 1 < nci) v.y = sp[1]; if (part * 4 + 2 < nci) v.z = sp[2]; }
-                }
-                split_store(v, xl + pix * CI_T + part * 4, xl_lo + pix * CI_T + part * 4);
-            } else {
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (in) {
-                    v = *(const uint4*)(xg + (((size_t)b * p.H + gy) * p.W + gx) * p.x_ld + ci0 + part * 8);
-                    if (part * 8 + 8 > nci) v = mask_bf16x8(v, nci - part * 8);
-                }
-                *(uint4*)(xl + pix * CI_T + part * 8) = v;
-            }
-        }
+            valid = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? nci - part * EPP : 0;
+            return xbp + ((size_t)(gy * p.W + gx) * p.x_ld + ci0 + part * EPP) * GES;
+        });
         __syncthreads();
         for (int s = s0; s < s1; ++s) {
-            const int q0 = 16 * s + 8 * kk;
-            const int4 t0 = *(const int4*)(tab + q0), t1 = *(const int4*)(tab + q0 + 4);
-            const int xo[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-            const uint16_t* ap = dyl + q0 * CO_T + wco * R * 32 + col;
-            const uint16_t* bp = xl + wci * R * 32 + col;
+            const int qa = 16 * s + 8 * kk + trq;                    // this lane's row of the first block; the second is 4 further
+            const int t0 = tab[qa], t1 = tab[qa + 4];
+            const char* ap = dyl + qa * PSA + (wco * R * 32 + trc) * 2;
+            const char* bp = xl + (wci * R * 32 + trc) * 2;
             bf16x8_t a[R], al[SPLIT ? R : 1];
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    a[r][e] = (short)ap[e * CO_T + r * 32];
-                    if constexpr (SPLIT) al[r][e] = (short)(ap + (dyl_lo - dyl))[e * CO_T + r * 32];
-                }
+            for (int r = 0; r < R; ++r) {
+                a[r] = lds_tr8(ap + r * 64, ap + 4 * PSA + r * 64);
+                if constexpr (SPLIT) al[r] = lds_tr8(ap + (dyl_lo - dyl) + r * 64, ap + (dyl_lo - dyl) + 4 * PSA + r * 64);
+            }
 #pragma unroll
             for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
                 for (int rc = 0; rc < R; ++rc) {
                     bf16x8_t bv, bl;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        bv[e] = (short)bp[xo[e] + tapoff[tp] + rc * 32];
-                        if constexpr (SPLIT) bl[e] = (short)(bp + (xl_lo - xl))[xo[e] + tapoff[tp] + rc * 32];
-                    }
+                    bv = lds_tr8(bp + t0 + tapoff[tp] + rc * 64, bp + t1 + tapoff[tp] + rc * 64);
+                    if constexpr (SPLIT) bl = lds_tr8(bp + (xl_lo - xl) + t0 + tapoff[tp] + rc * 64, bp + (xl_lo - xl) + t1 + tapoff[tp] + rc * 64);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         f32x16_t& c = acc[(tp * R + r) * R + rc];
@@ -632,7 +662,33 @@ __global__ void __launch_bounds__(256) conv_wgrad_bf16_kernel(WgradP p) {
                 }
         }
     }
-    float* out = p.part + ((size_t)split * WPX + wpx) * p.slice;    // one slice per pixel group
+    // The WPX waves that split the pixels of the patches add their sums through LDS (in wave order, two accumulator
+    // tiles per round), so that a workgroup writes ONE slice.
+    if constexpr (WPX > 1) {
+        constexpr int CH = 2, GROUPS = WCO * WCI;
+        float* red = (float*)wl8;                               // [4 waves][CH][16][64 lanes]
+#pragma unroll
+        for (int a0 = 0; a0 < NACC; a0 += CH) {
+            __syncthreads();
+            if (wpx > 0) {
+#pragma unroll
+                for (int a = a0; a < (a0 + CH < NACC ? a0 + CH : NACC); ++a)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) red[((wave * CH + (a - a0)) * 16 + e) * 64 + lane] = acc[a][e];
+            }
+            __syncthreads();
+            if (wpx == 0) {
+#pragma unroll
+                for (int w = 1; w < WPX; ++w)
+#pragma unroll
+                    for (int a = a0; a < (a0 + CH < NACC ? a0 + CH : NACC); ++a)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[a][e] += red[(((wave + GROUPS * w) * CH + (a - a0)) * 16 + e) * 64 + lane];
+            }
+        }
+        if (wpx > 0) return;
+    }
+    float* out = p.part + (size_t)split * p.slice;
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -641,10 +697,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_bf16_kernel(WgradP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = co0 + (wco * R + r) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-                if (co < p.Cout && ci < p.Cin) {
-                    float* o = out + ((size_t)co * p.Cin + ci) * TAPS;
+                if (co < p.Cout && ci < p.Cin) {       // [tap][Cout][Cin]: a half wave writes 32 consecutive floats
+                    float* o = out + (size_t)co * p.Cin + ci;
 #pragma unroll
-                    for (int tp = 0; tp < TAPS; ++tp) o[tp] = acc[(tp * R + r) * R + rc][e];
+                    for (int tp = 0; tp < TAPS; ++tp) o[(size_t)tp * p.Cout * p.Cin] = acc[(tp * R + r) * R + rc][e];
                 }
             }
         }
@@ -753,9 +809,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_first_kernel(WgradP p) {
 
 // dw[i] += sum over slices (fixed order).  Workgroup: 32 elements x G slice groups (G = 32 when there
 // are hundreds of slices, so that no thread walks more than a few dozen dependent additions).
+// A slice is [taps][cc] (cc = Cout * Cin); element (tap, j) belongs to dw[j * taps + tap] (taps = 1: same order).
 template <int G>
 __global__ void __launch_bounds__(32 * G) wgrad_fold_kernel(const float* __restrict__ part, size_t slice, int nslices,
-                                                            float* __restrict__ dw) {
+                                                            float* __restrict__ dw, int taps, int cc) {
     __shared__ float red[G][32];
     const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
     const size_t i = (size_t)blockIdx.x * 32 + e;
@@ -775,7 +832,8 @@ __global__ void __launch_bounds__(32 * G) wgrad_fold_kernel(const float* __restr
         float t = red[0][e];
 #pragma unroll
         for (int k = 1; k < G; ++k) t += red[k][e];
-        dw[i] += t;
+        const int tap = taps == 1 ? 0 : (int)(i / (size_t)cc);
+        dw[(i - (size_t)tap * cc) * taps + tap] += t;
     }
 }
 
@@ -1065,22 +1123,40 @@ int wgrad_plan(int batch, int h, int w, int cin, int cout, int ksize, int stride
         p.npix = (p.TH * p.TW + round - 1) / round * round;
         p.IH = (p.TH - 1) * stride + ksize;
         p.IW = (p.TW - 1) * stride + ksize;
-        o.lds = ((size_t)p.npix * co_t + ((size_t)p.IH * p.IW + 1) * ci_t) * es + (size_t)p.npix * sizeof(int);
+        if (o.first) o.lds = ((size_t)p.npix * co_t + ((size_t)p.IH * p.IW + 1) * ci_t) * es + (size_t)p.npix * sizeof(int);
+        else        // bf16 staging with padded rows; float32 inputs are staged as (hi, lo) bf16 pairs
+            o.lds = ((size_t)p.npix * wgrad_row_bytes(co_t, 1) + ((size_t)p.IH * p.IW + 1) * wgrad_row_bytes(ci_t, stride)) * (es / 2) +
+                    (size_t)p.npix * sizeof(int);
         if (o.lds <= 64 * 1024 || p.TH == 1) break;
     }
+    p.inv_tw = 1.0f / (float)p.TW; p.inv_iw = 1.0f / (float)p.IW;
+    if (!o.first && o.lds < 32 * 1024) o.lds = 32 * 1024;          // the waves' end-of-kernel reduction area
     if (o.lds > 160 * 1024) return ODAMD_E_SHAPE;
     p.tiles_x = (p.Wo + p.TW - 1) / p.TW;
     p.tiles_y = (p.Ho + p.TH - 1) / p.TH;
     p.ntiles = batch * p.tiles_x * p.tiles_y;
     p.ncin = o.first ? 1 : (cin + ci_t - 1) / ci_t;
     p.npairs = p.ncin * ((cout + co_t - 1) / co_t);
-    int nsplit = (512 + p.npairs - 1) / p.npairs;          // about two workgroups per CU
-    nsplit = (nsplit + 7) & ~7;
-    if (nsplit > p.ntiles) nsplit = p.ntiles;
-    p.nsplit = nsplit;
     p.slice = (size_t)cout * cin * taps;
+    int nmax = (512 + p.npairs - 1) / p.npairs;            // about two workgroups per CU
+    nmax = (nmax + 7) & ~7;
+    if (nmax > p.ntiles) nmax = p.ntiles;
+    int nsplit = nmax;
+    if (!o.first) {
+        // Splits trade patches per workgroup (serial: stage, barrier, multiply) against slices (written once and read
+        // once by the fold): pick the multiple of 8 with the smallest estimate, in microseconds.
+        const double staged_kb = ((double)p.npix * co_t + (double)p.IH * p.IW * ci_t) * es / 1024.0;
+        const double t_patch = 1.0 + staged_kb / 9.0;      // one workgroup's patch on a CU it shares with another
+        double best = 1e30;
+        for (int n = 8; n <= nmax; n += 8) {
+            const double serial = (double)((p.ntiles + n - 1) / n) * t_patch * (p.npairs * n > 256 ? 1.0 : 0.6);
+            const double slices = 2.0 * n * (double)p.slice * sizeof(float) / 6.0e6 + 0.01 * n;
+            if (serial + slices < best) { best = serial + slices; nsplit = n; }
+        }
+    }
+    p.nsplit = nsplit;
     o.grid = 8 * p.npairs * ((nsplit + 7) / 8);
-    o.nslices = nsplit * (4 / (o.wco * o.wci));
+    o.nslices = o.first ? nsplit * 4 : nsplit;
     return ODAMD_OK;
 }
 
@@ -1275,10 +1351,11 @@ int odamd_conv_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* 
     }
     int err = (int)hipGetLastError();
     if (err) return err;
+    const int taps = o.first ? 1 : ksize * ksize, cc = o.first ? (int)o.p.slice : cout * cin;   // the first-layer kernel writes the torch order
     if (o.nslices >= 256)
-        wgrad_fold_kernel<32><<<(unsigned)((o.p.slice + 31) / 32), 1024, 0, st>>>(o.p.part, o.p.slice, o.nslices, dw);
+        wgrad_fold_kernel<32><<<(unsigned)((o.p.slice + 31) / 32), 1024, 0, st>>>(o.p.part, o.p.slice, o.nslices, dw, taps, cc);
     else
-        wgrad_fold_kernel<8><<<(unsigned)((o.p.slice + 31) / 32), 256, 0, st>>>(o.p.part, o.p.slice, o.nslices, dw);
+        wgrad_fold_kernel<8><<<(unsigned)((o.p.slice + 31) / 32), 256, 0, st>>>(o.p.part, o.p.slice, o.nslices, dw, taps, cc);
     return (int)hipGetLastError();
 }
 
