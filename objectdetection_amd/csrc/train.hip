@@ -515,59 +515,16 @@ __device__ __forceinline__ void split_store(float4 v, uint16_t* hi, uint16_t* lo
     *(uint2*)lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
 }
 
+// 16-byte pieces per thread that one staging batch of the weight-gradient kernel holds in registers
+__host__ __device__ constexpr int wgrad_batch(int ks, bool split) { return split ? 6 : (ks == 3 ? 9 : 12); }
 __device__ __forceinline__ int div_small_t(int v, float inv) { return (int)(((float)v + 0.5f) * inv); }   // exact for v < 2^21, divisor < 2^12
-
-// Stages `total` 16-byte global pieces (PP per pixel row) into LDS rows of `ps` bytes.  where(pixel, part, valid) returns
-// the piece's address and the number of real elements in it (<= 0: none, the piece is zero).  SPLIT: the piece holds
-// four float32 values, staged as (hi, lo) bf16 pairs; otherwise eight bf16 values.
-template <bool SPLIT, int PP, typename F>
-__device__ __forceinline__ void stage_pieces(int tid, int total, int ps, char* hi, char* lo, F&& where) {
-    constexpr int NB = 12, EPP = SPLIT ? 4 : 8;
-    for (int b0 = 0; b0 < total; b0 += 256 * NB) {
-        uint4 v[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int i = b0 + tid + j * 256;
-            v[j] = make_uint4(0u, 0u, 0u, 0u);
-            if (i < total) {
-                int valid;
-                const char* src = where(i / PP, i % PP, valid);
-                if (valid > 0) {
-                    v[j] = *(const uint4*)src;
-                    if (valid < EPP) {
-                        if constexpr (SPLIT) {
-                            if (valid < 2) v[j].y = 0u;
-                            if (valid < 3) v[j].z = 0u;
-                            v[j].w = 0u;
-                        } else {
-                            v[j] = mask_bf16x8(v[j], valid);
-                        }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int i = b0 + tid + j * 256;
-            if (i < total) {
-                const int pix = i / PP, part = i % PP;
-                if constexpr (SPLIT) {
-                    const float4 f = make_float4(__uint_as_float(v[j].x), __uint_as_float(v[j].y), __uint_as_float(v[j].z), __uint_as_float(v[j].w));
-                    split_store(f, (uint16_t*)(hi + pix * ps + part * 8), (uint16_t*)(lo + pix * ps + part * 8));
-                } else {
-                    *(uint4*)(hi + pix * ps + part * 16) = v[j];
-                }
-            }
-        }
-    }
-}
 
 // SPLIT: x and dy are float32; every value is staged as two bf16 numbers hi = bf16(v), lo = bf16(v - hi)
 // and a product is taken as hi*hi + hi*lo + lo*hi on three bf16 MFMAs with float32 accumulation (the
 // dropped lo*lo term and the rounding of lo are ~2^-17 of the product): float32-grade weight gradients
 // at five times the rate of the float32 MFMA.
 template <int KS, int ST, int WCO, int WCI, int R, bool SPLIT>
-__global__ void __launch_bounds__(256) conv_wgrad_bf16_kernel(WgradP p) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_wgrad_bf16_kernel(WgradP p) {
     constexpr int TAPS = KS * KS, PAD = (KS - 1) / 2;
     constexpr int CO_T = 32 * WCO * R, CI_T = 32 * WCI * R, WPX = 4 / (WCO * WCI);
     constexpr int NACC = TAPS * R * R;
@@ -610,28 +567,88 @@ __global__ void __launch_bounds__(256) conv_wgrad_bf16_kernel(WgradP p) {
 
     const int steps = npix >> 4;
     const int s0 = wpx * (steps / WPX), s1 = s0 + steps / WPX;
-    for (int t = split; t < p.ntiles; t += p.nsplit) {
+    // Staging: the 16-byte pieces of the dY patch and of the x halo patch form one list, NB pieces per thread and
+    // batch; the global loads of a batch are all in flight before its first LDS store.  When a patch is a single
+    // batch, the loads of the workgroup's NEXT patch are issued before the matrix work of the current one and land in
+    // LDS after it.
+    constexpr int NB = wgrad_batch(KS, SPLIT);
+    const int nreal = p.TH * p.TW;                       // dY rows beyond the patch stay zero (cleared once below)
+    const int nd = nreal * PCO, total = nd + nhalo * PCI;
+    for (int i = tid; i < (npix - nreal) * (PSA / 16); i += 256) {
+        *(uint4*)(dyl + nreal * PSA + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (SPLIT) *(uint4*)(dyl_lo + nreal * PSA + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const bool single = total <= 256 * NB;
+    uint4 v[NB];
+    auto load_batch = [&](int t, int b0) {
         const int b = t / (p.tiles_x * p.tiles_y), tt = t % (p.tiles_x * p.tiles_y);
         const int oy0 = (tt / p.tiles_x) * p.TH, ox0 = (tt % p.tiles_x) * p.TW;
-        __syncthreads();
-        // Staging in batches: the global loads of up to NB pieces per thread are all in flight before the first LDS
-        // store (one memory round trip per batch instead of one per piece).
         const int iy0 = oy0 * ST - PAD, ix0 = ox0 * ST - PAD;
         const char* dyb = (const char*)p.dy + ((size_t)b * p.Ho * p.Wo) * p.dy_ld * GES;
         const char* xbp = (const char*)p.x + ((size_t)b * p.H * p.W) * p.x_ld * GES;
-        stage_pieces<SPLIT, PCO>(tid, npix * PCO, PSA, dyl, dyl_lo, [&](int pix, int part, int& valid) -> const char* {
-            const int ty = div_small_t(pix, p.inv_tw), tx = pix - ty * p.TW;
-            const int oy = oy0 + ty, ox = ox0 + tx;
-            valid = (ty < p.TH && oy < p.Ho && ox < p.Wo) ? nco - part * EPP : 0;
-            return dyb + ((size_t)(oy * p.Wo + ox) * p.dy_ld + co0 + part * EPP) * GES;
-        });
-        stage_pieces<SPLIT, PCI>(tid, nhalo * PCI, PSX, xl, xl_lo, [&](int pix, int part, int& valid) -> const char* {
-            const int hy = div_small_t(pix, p.inv_iw);
-            const int gy = iy0 + hy, gx = ix0 + pix - hy * p.IW;
-            valid = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? nci - part * EPP : 0;
-            return xbp + ((size_t)(gy * p.W + gx) * p.x_ld + ci0 + part * EPP) * GES;
-        });
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int i = b0 + tid + j * 256;
+            asm volatile("" : "+v"(i));        // recompute the piece's coordinates per patch: kept across patches they cost ~10 registers a piece
+            v[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (i >= total) continue;
+            int valid;
+            const char* src;
+            if (i < nd) {
+                const int pix = i / PCO, part = i % PCO;
+                const int ty = div_small_t(pix, p.inv_tw), tx = pix - ty * p.TW;
+                const int oy = oy0 + ty, ox = ox0 + tx;
+                valid = (oy < p.Ho && ox < p.Wo) ? nco - part * EPP : 0;
+                src = dyb + ((size_t)(oy * p.Wo + ox) * p.dy_ld + co0 + part * EPP) * GES;
+            } else {
+                const int k = i - nd, pix = k / PCI, part = k % PCI;
+                const int hy = div_small_t(pix, p.inv_iw);
+                const int gy = iy0 + hy, gx = ix0 + pix - hy * p.IW;
+                valid = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? nci - part * EPP : 0;
+                src = xbp + ((size_t)(gy * p.W + gx) * p.x_ld + ci0 + part * EPP) * GES;
+            }
+            if (valid > 0) {
+                v[j] = *(const uint4*)src;
+                if (valid < EPP) {                 // ragged channel tail: the rest of the piece belongs to a neighbour
+                    if constexpr (SPLIT) {
+                        if (valid < 2) v[j].y = 0u;
+                        if (valid < 3) v[j].z = 0u;
+                        v[j].w = 0u;
+                    } else {
+                        v[j] = mask_bf16x8(v[j], valid);
+                    }
+                }
+            }
+        }
+    };
+    auto store_batch = [&](int b0) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int i = b0 + tid + j * 256;
+            asm volatile("" : "+v"(i));
+            if (i >= total) continue;
+            const bool isd = i < nd;
+            const int k = isd ? i : i - nd;
+            const int pix = isd ? k / PCO : k / PCI, part = isd ? k % PCO : k % PCI;
+            const int off = pix * (isd ? PSA : PSX) + part * (SPLIT ? 8 : 16);
+            if constexpr (SPLIT) {
+                const float4 f = make_float4(__uint_as_float(v[j].x), __uint_as_float(v[j].y), __uint_as_float(v[j].z), __uint_as_float(v[j].w));
+                split_store(f, (uint16_t*)((isd ? dyl : xl) + off), (uint16_t*)((isd ? dyl_lo : xl_lo) + off));
+            } else {
+                *(uint4*)((isd ? dyl : xl) + off) = v[j];
+            }
+        }
+    };
+    if (single && split < p.ntiles) load_batch(split, 0);
+    for (int t = split; t < p.ntiles; t += p.nsplit) {
+        __syncthreads();                                   // the previous patch has been consumed
+        if (single) {
+            store_batch(0);
+        } else {
+            for (int b0 = 0; b0 < total; b0 += 256 * NB) { load_batch(t, b0); store_batch(b0); }
+        }
         __syncthreads();
+        if (single && t + p.nsplit < p.ntiles) load_batch(t + p.nsplit, 0);
         for (int s = s0; s < s1; ++s) {
             const int qa = 16 * s + 8 * kk + trq;                    // this lane's row of the first block; the second is 4 further
             const int t0 = tab[qa], t1 = tab[qa + 4];
@@ -1100,6 +1117,11 @@ int wgrad_plan(int batch, int h, int w, int cin, int cout, int ksize, int stride
     WgradP& p = o.p;
     p = {};
     p.B = batch; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout;
+    if (ksize == 1) {          // no spatial structure: the pixels of the whole batch are one row
+        const size_t flat = (size_t)batch * h * w;
+        if (flat >= ((size_t)1 << 30)) return ODAMD_E_SHAPE;
+        p.B = batch = 1; p.H = h = 1; p.W = w = (int)flat;
+    }
     const int pad = (ksize - 1) / 2, taps = ksize * ksize;
     p.Ho = (h + 2 * pad - ksize) / stride + 1;
     p.Wo = (w + 2 * pad - ksize) / stride + 1;
@@ -1109,25 +1131,44 @@ int wgrad_plan(int batch, int h, int w, int cin, int cout, int ksize, int stride
     else if (cout <= 32 && cin <= 32) { o.r = 1; o.wco = 1; o.wci = 1; }
     else { o.r = 2; o.wco = cout > 64 ? 2 : 1; o.wci = cin > 64 ? 2 : 1; }
     const int co_t = 32 * o.wco * o.r, ci_t = o.first ? 8 : 32 * o.wci * o.r;
-    // patch width: the largest divisor of the row length in [8, 40], else 32 with guarded edges
-    p.TW = 0;
-    for (int d = p.Wo < 40 ? p.Wo : 40; d >= 8; --d)
-        if (p.Wo % d == 0) { p.TW = d; break; }
-    if (p.TW == 0) p.TW = p.Wo < 32 ? p.Wo : 32;
-    // patch height: as many rows as keep the staging under 64 KB (two workgroups per CU), at most 128
-    // pixels (float32) or 256 (bf16); the pixel count is padded to whole K steps for every pixel group
+    // the pixel count of a patch is padded to whole K steps (16 pixels) for every pixel group of waves
     const int es = dtype == ODAMD_DTYPE_F32 ? 4 : 2;
-    const int round = o.first && dtype == ODAMD_DTYPE_F32 ? 8 : 64, maxpix = dtype == ODAMD_DTYPE_F32 ? 128 : 256;
-    for (p.TH = (maxpix / p.TW > 1 ? maxpix / p.TW : 1);; --p.TH) {
-        if (p.TH > p.Ho) continue;
-        p.npix = (p.TH * p.TW + round - 1) / round * round;
-        p.IH = (p.TH - 1) * stride + ksize;
-        p.IW = (p.TW - 1) * stride + ksize;
-        if (o.first) o.lds = ((size_t)p.npix * co_t + ((size_t)p.IH * p.IW + 1) * ci_t) * es + (size_t)p.npix * sizeof(int);
-        else        // bf16 staging with padded rows; float32 inputs are staged as (hi, lo) bf16 pairs
-            o.lds = ((size_t)p.npix * wgrad_row_bytes(co_t, 1) + ((size_t)p.IH * p.IW + 1) * wgrad_row_bytes(ci_t, stride)) * (es / 2) +
-                    (size_t)p.npix * sizeof(int);
-        if (o.lds <= 64 * 1024 || p.TH == 1) break;
+    const int round = o.first ? (dtype == ODAMD_DTYPE_F32 ? 8 : 64) : 16 * (4 / (o.wco * o.wci));
+    const int maxpix = dtype == ODAMD_DTYPE_F32 ? 128 : 256;
+    const size_t lds_target = 80 * 1024;          // two workgroups per CU
+    auto lds_bytes = [&]() -> size_t {
+        if (o.first) return ((size_t)p.npix * co_t + ((size_t)p.IH * p.IW + 1) * ci_t) * es + (size_t)p.npix * sizeof(int);
+        // bf16 staging with padded rows; float32 inputs are staged as (hi, lo) bf16 pairs
+        return ((size_t)p.npix * wgrad_row_bytes(co_t, 1) + ((size_t)p.IH * p.IW + 1) * wgrad_row_bytes(ci_t, stride)) * (es / 2) +
+               (size_t)p.npix * sizeof(int);
+    };
+    // a patch whose pieces fit one staging batch is prefetched while the previous one is multiplied
+    const int epp = dtype == ODAMD_DTYPE_F32 ? 4 : 8;
+    const size_t one_batch = (size_t)256 * wgrad_batch(ksize, dtype == ODAMD_DTYPE_F32);
+    auto pieces = [&]() -> size_t { return (size_t)p.TH * p.TW * (co_t / epp) + (size_t)p.IH * p.IW * (ci_t / epp); };
+    if (ksize == 1) {
+        // one row of pixels: a patch is a run of TW of them, as many as fit
+        p.TH = 1; p.IH = 1;
+        for (p.TW = maxpix;; p.TW -= round) {
+            p.npix = p.TW; p.IW = p.TW;
+            o.lds = lds_bytes();
+            if ((o.lds <= lds_target && pieces() <= one_batch) || p.TW <= round) break;
+        }
+    } else {
+        // patch width: the largest divisor of the row length in [8, 40], else 32 with guarded edges
+        p.TW = 0;
+        for (int d = p.Wo < 40 ? p.Wo : 40; d >= 8; --d)
+            if (p.Wo % d == 0) { p.TW = d; break; }
+        if (p.TW == 0) p.TW = p.Wo < 32 ? p.Wo : 32;
+        // patch height: as many rows as fit, at most 128 pixels (float32) or 256 (bf16)
+        for (p.TH = (maxpix / p.TW > 1 ? maxpix / p.TW : 1);; --p.TH) {
+            if (p.TH > p.Ho) continue;
+            p.npix = (p.TH * p.TW + round - 1) / round * round;
+            p.IH = (p.TH - 1) * stride + ksize;
+            p.IW = (p.TW - 1) * stride + ksize;
+            o.lds = lds_bytes();
+            if ((o.lds <= lds_target && (o.first || pieces() <= one_batch)) || p.TH == 1) break;
+        }
     }
     p.inv_tw = 1.0f / (float)p.TW; p.inv_iw = 1.0f / (float)p.IW;
     if (!o.first && o.lds < 32 * 1024) o.lds = 32 * 1024;          // the waves' end-of-kernel reduction area
