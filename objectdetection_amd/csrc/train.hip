@@ -749,7 +749,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_first_kernel(WgradP p) {
     const bool live = col < 9 * p.Cin;
     const int lane_off = live ? ((tap / 3) * p.IW + (tap % 3)) * 8 + c : 0;
     for (int q = tid; q < npix; q += 256) {
-        const int ty = q / p.TW, tx = q - ty * p.TW;
+        const int ty = div_small_t(q, p.inv_tw), tx = q - ty * p.TW;
         tab[q] = ty < p.TH ? ty * p.IW + tx : 0;     // padding pixels: dY is zero there, any staged (finite) x will do
     }
     f32x16_t acc;
@@ -757,44 +757,72 @@ __global__ void __launch_bounds__(256) conv_wgrad_first_kernel(WgradP p) {
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
     const int steps = npix / KSTEP;
     const int s0 = wave * (steps / 4), s1 = s0 + steps / 4;
-    for (int t = split; t < p.ntiles; t += p.nsplit) {
+    // staging as in conv_wgrad_bf16_kernel: one list of 16-byte pieces, batches of NB per thread, the next patch's
+    // loads in flight during the matrix work when a patch is one batch
+    constexpr int NB = 6;
+    constexpr int PPP = 32 * ES / 16;                    // 16-byte pieces per dY pixel
+    constexpr int XPP = 8 * ES / 16;                     // pieces per image pixel (8 channels)
+    constexpr int per = 16 / ES;
+    const int nreal = p.TH * p.TW;
+    const int nd = nreal * PPP, total = nd + nhalo * XPP;
+    const bool single = total <= 256 * NB;
+    for (int i = tid; i < (npix - nreal) * PPP; i += 256) *(uint4*)(dyl + (size_t)nreal * 32 * ES + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+    uint4 v[NB];
+    auto load_batch = [&](int t, int b0) {
         const int b = t / (p.tiles_x * p.tiles_y), tt = t % (p.tiles_x * p.tiles_y);
         const int oy0 = (tt / p.tiles_x) * p.TH, ox0 = (tt % p.tiles_x) * p.TW;
-        __syncthreads();
-        constexpr int PPP = 32 * ES / 16;                    // 16-byte pieces per dY pixel
-        for (int i = tid; i < npix * PPP; i += 256) {
-            const int pix = i / PPP, part = i % PPP;
-            const int ty = pix / p.TW, tx = pix - ty * p.TW;
-            const int oy = oy0 + ty, ox = ox0 + tx;
-            const int per = 16 / ES;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (ty < p.TH && oy < p.Ho && ox < p.Wo && part * per < nco) {
-                v = *(const uint4*)((const char*)p.dy + ((((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0 + part * per) * ES);
-                if (part * per + per > nco) {
-                    if constexpr (DT == ODAMD_DTYPE_F32) {
-                        const int valid = nco - part * per;
-                        if (valid < 2) v.y = 0u;
-                        if (valid < 3) v.z = 0u;
-                        v.w = 0u;
-                    } else {
-                        v = mask_bf16x8(v, nco - part * per);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int i = b0 + tid + j * 256;
+            asm volatile("" : "+v"(i));
+            v[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (i >= total) continue;
+            if (i < nd) {
+                const int pix = i / PPP, part = i % PPP;
+                const int ty = div_small_t(pix, p.inv_tw), tx = pix - ty * p.TW;
+                const int oy = oy0 + ty, ox = ox0 + tx;
+                const int valid = (oy < p.Ho && ox < p.Wo) ? nco - part * per : 0;
+                if (valid > 0) {
+                    v[j] = *(const uint4*)((const char*)p.dy + ((((size_t)b * p.Ho + oy) * p.Wo + ox) * p.dy_ld + co0 + part * per) * ES);
+                    if (valid < per) {
+                        if constexpr (DT == ODAMD_DTYPE_F32) {
+                            if (valid < 2) v[j].y = 0u;
+                            if (valid < 3) v[j].z = 0u;
+                            v[j].w = 0u;
+                        } else {
+                            v[j] = mask_bf16x8(v[j], valid);
+                        }
                     }
                 }
+            } else {
+                const int k = i - nd, pix = k / XPP, part = k % XPP;
+                const int hy = div_small_t(pix, p.inv_iw);
+                const int gy = oy0 - 1 + hy, gx = ox0 - 1 + pix - hy * p.IW;
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                    v[j] = *(const uint4*)((const char*)p.x + ((((size_t)b * p.H + gy) * p.W + gx) * p.x_ld) * ES + part * 16);
             }
-            *(uint4*)(dyl + ((size_t)pix * 32 + part * per) * ES) = v;
         }
-        const int iy0 = oy0 - 1, ix0 = ox0 - 1;
-        constexpr int XPP = 8 * ES / 16;                     // pieces per image pixel (8 channels)
-        for (int i = tid; i < nhalo * XPP; i += 256) {
-            const int pix = i / XPP, part = i % XPP;
-            const int hy = pix / p.IW;
-            const int gy = iy0 + hy, gx = ix0 + pix - hy * p.IW;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                v = *(const uint4*)((const char*)p.x + ((((size_t)b * p.H + gy) * p.W + gx) * p.x_ld) * ES + part * 16);
-            *(uint4*)(xl + ((size_t)pix * 8) * ES + part * 16) = v;
+    };
+    auto store_batch = [&](int b0) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int i = b0 + tid + j * 256;
+            asm volatile("" : "+v"(i));
+            if (i >= total) continue;
+            if (i < nd) *(uint4*)(dyl + ((size_t)(i / PPP) * 32 + (i % PPP) * per) * ES) = v[j];
+            else *(uint4*)(xl + ((size_t)((i - nd) / XPP) * 8) * ES + ((i - nd) % XPP) * 16) = v[j];
+        }
+    };
+    if (single && split < p.ntiles) load_batch(split, 0);
+    for (int t = split; t < p.ntiles; t += p.nsplit) {
+        __syncthreads();
+        if (single) {
+            store_batch(0);
+        } else {
+            for (int b0 = 0; b0 < total; b0 += 256 * NB) { load_batch(t, b0); store_batch(b0); }
         }
         __syncthreads();
+        if (single && t + p.nsplit < p.ntiles) load_batch(t + p.nsplit, 0);
         for (int s = s0; s < s1; ++s) {
             const int q0 = KSTEP * s + KL * kk;
             if constexpr (DT == ODAMD_DTYPE_F32) {
@@ -1179,7 +1207,9 @@ int wgrad_plan(int batch, int h, int w, int cin, int cout, int ksize, int stride
     p.ncin = o.first ? 1 : (cin + ci_t - 1) / ci_t;
     p.npairs = p.ncin * ((cout + co_t - 1) / co_t);
     p.slice = (size_t)cout * cin * taps;
-    int nmax = (512 + p.npairs - 1) / p.npairs;            // about two workgroups per CU
+    // about two workgroups per CU; the first-layer kernel stages ~13 KB per patch and needs eight per CU to keep
+    // enough loads in flight
+    int nmax = ((o.first ? 2048 : 512) + p.npairs - 1) / p.npairs;
     nmax = (nmax + 7) & ~7;
     if (nmax > p.ntiles) nmax = p.ntiles;
     int nsplit = nmax;
