@@ -638,23 +638,41 @@ class TrainPlan:
         pending = None
         if reducer is not None:
             pending = self._bucket_plan(reducer)
+        # The weight gradients are off the critical path (layer L's data gradient and layer L-1's BatchNorm backward do
+        # not read them): they run on a second stream, one after the other, each behind an event recorded after the
+        # BatchNorm backward that produced its dY.  Small layers do not fill the chip, so the two streams overlap.
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        side_busy = False
         for i, (fn, args, name, extra) in enumerate(self.bwd):
             if fn == 'bn_bwd':
                 self._bn_bwd(*args, stream)
             elif fn == 'mark':
                 if pending is not None:
-                    for bucket in pending.pop(i, ()):
+                    buckets = pending.pop(i, ())
+                    if buckets and side_busy:
+                        main.wait_stream(side)          # the buckets' weight gradients are complete
+                        side_busy = False
+                    for bucket in buckets:
                         reducer.ready(bucket)
-            elif name == 'wgrad' and extra is not None:
-                _, weight, src, n = extra
-                cout, _, k, _ = weight.shape
-                tmp = self.bias_tmp.get(('wseg', cout, n, k))
-                if tmp is None:
-                    tmp = self.bias_tmp[('wseg', cout, n, k)] = torch.zeros((cout, n, k, k), dtype=torch.float32, device=self.dev)
-                tmp.zero_()
-                args[4] = tmp.data_ptr()
-                check(fn(*args, stream), name)
-                weight.grad[:, src:src + n].add_(tmp)
+            elif name == 'wgrad':
+                ev = self._events[i] if i in self._events else self._events.setdefault(i, torch.cuda.Event())
+                ev.record(main)
+                side.wait_event(ev)
+                side_busy = True
+                with torch.cuda.stream(side):
+                    if extra is None:
+                        check(fn(*args, _stream()), name)
+                        continue
+                    _, weight, src, n = extra
+                    cout, _, k, _ = weight.shape
+                    tmp = self.bias_tmp.get(('wseg', cout, n, k))
+                    if tmp is None:
+                        tmp = self.bias_tmp[('wseg', cout, n, k)] = torch.zeros((cout, n, k, k), dtype=torch.float32, device=self.dev)
+                    tmp.zero_()
+                    args[4] = tmp.data_ptr()
+                    check(fn(*args, _stream()), name)
+                    weight.grad[:, src:src + n].add_(tmp)
             elif name == 'bias_grad':
                 _, bias, cout, cphys = extra
                 tmp = self.bias_tmp.get(id(bias))
@@ -666,6 +684,14 @@ class TrainPlan:
                 bias.grad.add_(tmp[:cout])
             else:
                 check(fn(*args, stream), name)
+        if side_busy:
+            main.wait_stream(side)
+
+    def _side_stream(self):
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+            self._events = {}
+        return self._side
 
     def _bucket_plan(self, reducer):
         """launch index of the 'mark' after which a bucket's last gradient has been written."""
