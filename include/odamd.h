@@ -342,9 +342,13 @@ int odamd_ema_update(float* ema, const float* src, size_t n, double decay, void*
 /* Packs master float32 weights into the kernels' layouts for every convolution at once.
  * table_dev: device array of n_entries descriptors of odamd_pack_desc_bytes() bytes each:
  *   { const float* w; void* fwd; void* bwd; int cout, cin, k, cin_phys, cout_phys, n_seg;
- *     int seg_off[8], seg_len[8]; int fwd_f32, reserved; }
+ *     int seg_off[8], seg_len[8]; int fwd_f32, fwd_frag, bwd_frag, reserved; }
  * fwd: [cout][ky][kx][cin_phys]; bwd: [cin_phys][2-ky][2-kx][cout_phys] (data-gradient weights), both in
- * `dtype`; fwd_f32 = 1 keeps the forward copy float32 (odamd_conv_first_forward takes float32 weights). */
+ * `dtype`; fwd_f32 = 1 keeps the forward copy float32 (odamd_conv_first_forward takes float32 weights).
+ * fwd_frag / bwd_frag != 0 (bf16 only) write that copy in the fragment order of odamd_conv_weight_layout
+ * instead: value = cout_groups | chunk_bytes << 8 as that call returned them for the launch which will read the
+ * copy (rows = its output channels, columns = its input channels); the destination must be zero-filled and
+ * hold the row count rounded up to 32 * cout_groups. */
 int odamd_pack_weights(const void* table_dev, int n_entries, int dtype, void* stream);
 size_t odamd_pack_desc_bytes(void);
 

@@ -43,7 +43,7 @@ class PackDesc(C.Structure):
     """One entry of the odamd_pack_weights table."""
     _fields_ = [('w', c_void_p), ('fwd', c_void_p), ('bwd', c_void_p), ('cout', c_int), ('cin', c_int), ('k', c_int),
                 ('cin_phys', c_int), ('cout_phys', c_int), ('n_seg', c_int), ('seg_off', c_int * 8),
-                ('seg_len', c_int * 8), ('fwd_f32', c_int), ('reserved', c_int)]
+                ('seg_len', c_int * 8), ('fwd_f32', c_int), ('fwd_frag', c_int), ('bwd_frag', c_int), ('reserved', c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/odamd.h declares must appear here.

@@ -272,6 +272,8 @@ __host__ __device__ constexpr int max_in_pix(int ks, int st, int pg) {
     return ks == 1 ? 32 * pg : (st == 1 ? (pg == 8 ? 400 : 232) : (pg == 4 ? 608 : 1200));
 }
 
+constexpr int UPSKIP_MAX_PIX = 160;     // real input pixels under an even output tile of at most 256 pixels: (TH/2 + 1) * (TW/2 + 1)
+
 // CG: 32-channel groups per workgroup, PG: 32-pixel groups per workgroup,
 // WP x WC = 4 waves over (pixel groups, channel groups), CKB: bytes of input channels per chunk.
 //
@@ -282,7 +284,7 @@ __host__ __device__ constexpr int max_in_pix(int ks, int st, int pg) {
 // Epilogue: each wave transposes its 32-pixel x (32*CGW)-channel results through a private LDS
 // slice so that global stores are 16 bytes per lane and whole 64..256-byte runs per pixel.
 template <int DT, int KS, int ST, int CG, int PG, int WP, int WC, int CKB, bool POOL, bool UPSKIP = false>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
+__global__ void __launch_bounds__(256, UPSKIP ? (DT == ODAMD_DTYPE_BF16 ? 3 : 2) : 1) conv_igemm_kernel(ConvP p) {
     constexpr int ES = Elem<DT>::SIZE;
     constexpr int TAPS = KS * KS;
     constexpr int PS = CKB + 16;            // LDS bytes per staged pixel
@@ -290,7 +292,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
     constexpr int PGW = PG / WP, CGW = CG / WC;
     constexpr int PARTS = CKB / 16;
     constexpr int PAD = (KS - 1) / 2;
-    constexpr int NP_IN = (max_in_pix(KS, ST, PG) * PARTS + 255) / 256;
+    constexpr int NP_IN = ((UPSKIP ? UPSKIP_MAX_PIX : max_in_pix(KS, ST, PG)) * PARTS + 255) / 256;
     constexpr int NP_W = (32 * CG * TAPS * PARTS + 255) / 256;
     static_assert(WP * WC == 4, "four waves");
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -327,7 +329,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
         const int oy = oy0 + ty, ox = ox0 + tx;
         opix[i] = (ty < p.TH && oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
         if (ty >= p.TH) { ty = 0; tx = 0; }
-        b_off[i] = ((ty * ST) * p.IW + tx * ST) * PS + 16 * h;
+        // UPSKIP stages the REAL input pixels only: output (ty, tx) of class (py, px) reads patch pixel
+        // (ty / 2 + (py & (ky >> 1)), tx / 2 + (px & (kx >> 1))) for its taps
+        if (UPSKIP) b_off[i] = ((ty >> 1) * p.IW + (tx >> 1)) * PS + 16 * h;
+        else b_off[i] = ((ty * ST) * p.IW + tx * ST) * PS + 16 * h;
     }
 #pragma unroll
     for (int i = 0; i < CGW; ++i) a_off[i] = ((wc * CGW + i) * 32 + r) * WRS + 16 * h;
@@ -343,7 +348,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
         const int iy = div_small(pix, p.inv_iw), ix = pix - iy * p.IW;
         const int gy = iy0 + iy, gx = ix0 + ix;
         const bool inside = i < n_in && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        if (POOL) in_g[j] = inside ? ((2 * gy) * p.Wr + 2 * gx) * p.x_ld * ES + part * 16 : -1;
+        if (UPSKIP) {
+            const int ry = (oy0 >> 1) + iy, rx = (ox0 >> 1) + ix;
+            in_g[j] = (i < n_in && ry < p.Hr && rx < p.Wr) ? (ry * p.Wr + rx) * p.x_ld * ES + part * 16 : -1;
+        } else if (POOL) in_g[j] = inside ? ((2 * gy) * p.Wr + 2 * gx) * p.x_ld * ES + part * 16 : -1;
         else if (p.upz) in_g[j] = (inside && !((gy | gx) & 1)) ? ((gy >> 1) * p.Wr + (gx >> 1)) * p.x_ld * ES + part * 16 : -1;
         else in_g[j] = inside ? (gy * p.W + gx) * p.x_ld * ES + part * 16 : -1;
     }
@@ -427,14 +435,18 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvP p) {
                 u32x4 a[CGW], bb[PGW];
 #pragma unroll
                 for (int j = 0; j < CGW; ++j) a[j] = *(const u32x4*)(lds_w + a_off[j] + tap * CKB + s * 32);
+                if (!UPSKIP) {
 #pragma unroll
-                for (int i = 0; i < PGW; ++i) bb[i] = *(const u32x4*)(lds_in + b_off[i] + tap_off + s * 32);
+                    for (int i = 0; i < PGW; ++i) bb[i] = *(const u32x4*)(lds_in + b_off[i] + tap_off + s * 32);
+                }
 #pragma unroll
                 for (int i = 0; i < PGW; ++i) {
                     if (UPSKIP) {
                         // tap (ky, kx) meets data only where (row + ky) and (column + kx) are odd
                         const int g = wp * PGW + i;
                         if (!((((g >> 1) + tap / KS) & 1) && ((g + tap % KS) & 1))) continue;
+                        const int shift = ((((g >> 1) & 1) & ((tap / KS) >> 1)) * p.IW + ((g & 1) & ((tap % KS) >> 1))) * PS;
+                        bb[i] = *(const u32x4*)(lds_in + b_off[i] + shift + s * 32);
                     }
 #pragma unroll
                     for (int j = 0; j < CGW; ++j) {
@@ -1317,12 +1329,14 @@ int launch_conv(ConvP p, hipStream_t st) {
     p.upskip = 0;
     if (KS == 3 && ST == 1 && p.upz && PG % 4 == 0) {   // even tiles make the parity-class tap skipping possible
         t = choose_tile(p.Ho, p.Wo, 32 * PG, KS, ST, PS, w_bytes, max_in_pix(KS, ST, PG), true);
+        if (t.ok && (t.th / 2 + 1) * (t.tw / 2 + 1) > UPSKIP_MAX_PIX) t.ok = false;
         p.upskip = t.ok;
     }
     if (!t.ok) t = choose_tile(p.Ho, p.Wo, 32 * PG, KS, ST, PS, w_bytes, max_in_pix(KS, ST, PG));
     if (!t.ok) return ODAMD_E_SHAPE;
     p.TH = t.th; p.TW = t.tw; p.IH = t.ih; p.IW = t.iw;
-    p.inv_tw = 1.0f / (float)t.tw; p.inv_iw = 1.0f / (float)t.iw;
+    if (p.upskip) { p.IH = t.th / 2 + 1; p.IW = t.tw / 2 + 1; }      // the real pixels under the tile, no inserted zeros
+    p.inv_tw = 1.0f / (float)t.tw; p.inv_iw = 1.0f / (float)p.IW;
     p.tiles_x = (p.Wo + t.tw - 1) / t.tw;
     p.tiles_y = (p.Ho + t.th - 1) / t.th;
     p.ncb = (p.Cout + 32 * CG - 1) / (32 * CG);
@@ -1332,7 +1346,7 @@ int launch_conv(ConvP p, hipStream_t st) {
         p.fast_epi = !p.nchw && fast_epilogue_ok(npix, p.y_ld, ES, p.Cout, 32 * (CG / WC), p.accum);
         p.ybytes = p.fast_epi ? (unsigned)((npix - 1) * p.y_ld * ES + (size_t)p.Cout * ES) : 0u;
     }
-    size_t lds = (((size_t)t.ih * t.iw * PS + 255) & ~(size_t)255) + w_bytes;
+    size_t lds = (((size_t)p.IH * p.IW * PS + 255) & ~(size_t)255) + w_bytes;
     const size_t epi = (size_t)4 * 32 * ((CG / WC) * 32 * 4 + 16);    // the waves' f32 transpose slices
     if (lds < epi) lds = epi;
     if constexpr (KS == 3 && ST == 1 && PG % 4 == 0 && !POOL) {

@@ -1072,8 +1072,20 @@ struct PackDesc {
     int n_seg;            // cin is spread over segments of the consumer's input buffer
     int seg_off[8], seg_len[8];
     int fwd_f32;          // 1: the forward copy stays float32 whatever the dtype (first-layer kernel)
+    int fwd_frag;         // 0: plain [cout][tap][cin_phys]; else groups | chunk_bytes << 8 of odamd_conv_weight_layout (bf16)
+    int bwd_frag;         // same for the data-gradient copy (plain: [cin_phys][flipped tap][cout_phys])
     int reserved;
 };
+
+// Index of element (row, tap, column) in the fragment-ordered layout [rows / 32G][chunk][G][tap][k-step][2][32][8]
+// (rows = output channels of the launch, columns = its input channels, `cols` of them).
+__device__ __forceinline__ size_t frag_index(int frag, int row, int tap, int col, int taps, int cols) {
+    const int groups = frag & 255, chunk = frag >> 8;
+    const int ksn = chunk / 32, nch = cols * 2 / chunk, cpc = chunk / 2;
+    const int cb = row / (32 * groups), g = (row >> 5) % groups, r = row & 31;
+    const int ch = col / cpc, s = (col % cpc) >> 4, half = (col >> 3) & 1, e = col & 7;
+    return ((((((size_t)cb * nch + ch) * groups + g) * taps + tap) * ksn + s) * 2 + half) * 256 + r * 8 + e;
+}
 
 __global__ void __launch_bounds__(256) pack_weights_kernel(const PackDesc* __restrict__ table, int dtype) {
     const PackDesc d = table[blockIdx.y];
@@ -1090,11 +1102,12 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const PackDesc* __res
             rem -= d.seg_len[s];
         }
         if (d.fwd) {
-            const size_t o = ((size_t)co * kk + t) * d.cin_phys + phys;
+            const size_t o = d.fwd_frag ? frag_index(d.fwd_frag, co, t, phys, kk, d.cin_phys) : ((size_t)co * kk + t) * d.cin_phys + phys;
             if (dtype == ODAMD_DTYPE_F32 || d.fwd_f32) ((float*)d.fwd)[o] = v; else ((uint16_t*)d.fwd)[o] = f32_to_bf16(v);
         }
         if (d.bwd) {
-            const size_t o = ((size_t)phys * kk + (kk - 1 - t)) * d.cout_phys + co;
+            const size_t o = d.bwd_frag ? frag_index(d.bwd_frag, phys, kk - 1 - t, co, kk, d.cout_phys)
+                                        : ((size_t)phys * kk + (kk - 1 - t)) * d.cout_phys + co;
             if (dtype == ODAMD_DTYPE_F32) ((float*)d.bwd)[o] = v; else ((uint16_t*)d.bwd)[o] = f32_to_bf16(v);
         }
     }

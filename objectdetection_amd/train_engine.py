@@ -307,12 +307,18 @@ class TrainPlan:
                                       self.dtype], 'first', 0))
                 else:
                     x = op['x']        # may hold zero-padded gaps (pruned, irregular widths): the packed weights
-                    wf = torch.zeros(cout * k * k * x.cphys, dtype=self.tdt, device=dev)   # have zero columns there
-                    wb = torch.zeros(x.cphys * k * k * cphys, dtype=self.tdt, device=dev)
-                    pack.append(self._pack_desc(m.conv.weight, wf, wb, x, cout))
-                    op['wf'], op['wb'] = wf, wb
-                    d = self._conv_desc(self._aptr(x), wf, None, raw.data_ptr(), x.h, x.w, x.cphys, cout, self._ld(x),
+                    #                    have zero columns there
+                    d = self._conv_desc(self._aptr(x), None, None, raw.data_ptr(), x.h, x.w, x.cphys, cout, self._ld(x),
                                         cphys, k, op['s'])
+                    wf, ffrag = self._weights_for(d, cout, k * k * x.cphys)
+                    # data gradient: a convolution of dY (cphys channels) with the flipped, transposed weights
+                    dg = self._conv_desc(raw.data_ptr(), None, None, self._gptr(x), ho, wo, cphys, x.cphys, cphys,
+                                         self._ld(x), k, 1, upz=int(op['s'] == 2), accum=int(id(op) not in self.dgrad_stores))
+                    wb, bfrag = self._weights_for(dg, x.cphys, k * k * cphys)
+                    pd = self._pack_desc(m.conv.weight, wf, wb, x, cout)
+                    pd.fwd_frag, pd.bwd_frag = ffrag, bfrag
+                    pack.append(pd)
+                    op['wf'], op['wb'], op['dgrad_desc'] = wf, wb, dg
                     self.fwd.append((lib.odamd_conv_forward, [C.byref(d)], 'conv', None))
                 self.fwd.append(('bn_fwd', (op, npix, cout, cphys), 'bn', None))
             elif kind == 'head':
@@ -386,9 +392,30 @@ class TrainPlan:
             d.seg_off[i], d.seg_len[i] = off, n
         return d
 
+    def _weights_for(self, d, rows, row_len):
+        """Allocates the weight copy a launch reads and decides its layout: the fragment order of the kernels with
+        packed weights where one of them serves the launch (bf16; they apply scale and shift, here 1 and 0), else the
+        plain [rows][row_len] order.  Returns (tensor, PackDesc fragment code)."""
+        frag = 0
+        if self.dtype == BF16 and not d.in_upzero2 and not d.accumulate:
+            if getattr(self, '_unit', None) is None:
+                self._unit = (torch.ones(4096, dtype=torch.float32, device=self.dev),
+                              torch.zeros(4096, dtype=torch.float32, device=self.dev))
+            g, cb = C.c_int(0), C.c_int(0)
+            d.scale, d.shift = self._unit[0].data_ptr(), self._unit[1].data_ptr()
+            if lib.odamd_conv_weight_layout(C.byref(d), C.byref(g), C.byref(cb)):
+                frag = g.value | (cb.value << 8)
+                rows = _round_up(rows, 32 * g.value)
+                d.w_packed = 1
+            else:
+                d.scale, d.shift = None, None
+        w = torch.zeros(rows * row_len, dtype=self.tdt, device=self.dev)
+        d.w = w.data_ptr()
+        return w, frag
+
     def _conv_desc(self, x_ptr, w, shift, y_ptr, h, w_in, cin, cout, x_ld, y_ld, k, s, nchw=0, upz=0, accum=0):
         d = _lib.ConvDesc()
-        d.x, d.w, d.scale = x_ptr, w.data_ptr(), None
+        d.x, d.w, d.scale = x_ptr, (w.data_ptr() if w is not None else None), None
         d.shift = shift.data_ptr() if shift is not None else None
         d.y = y_ptr
         d.batch, d.h, d.w_in, d.cin, d.cout = self.batch, h, w_in, cin, cout
@@ -487,10 +514,7 @@ class TrainPlan:
                                         [self._aptr(x) + off * self.es, self._ld(x), raw.data_ptr(), cphys, None, B, x.h,
                                          x.w, n, cout, k, op['s'], self.dtype], 'wgrad', ('columns', m.conv.weight, src, n)))
                             src += n
-                    d = self._conv_desc(raw.data_ptr(), op['wb'], None, self._gptr(x), raw.shape[1], raw.shape[2], cphys,
-                                        x.cphys, cphys, self._ld(x), k, 1, upz=int(op['s'] == 2),
-                                        accum=int(id(op) not in self.dgrad_stores))
-                    bwd.append((lib.odamd_conv_forward, [C.byref(d)], 'dgrad', None))
+                    bwd.append((lib.odamd_conv_forward, [C.byref(op['dgrad_desc'])], 'dgrad', None))
                 bwd.append(('mark', (m.conv.weight, m.bn.weight, m.bn.bias), 'mark', None))
             elif kind == 'head':
                 m, x = op['mod'], op['x']
