@@ -7,6 +7,31 @@
 
 #define ODAMD_ABI_VERSION 2
 
+#include <mutex>
+// Raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) on the current device only when the
+// limit set so far is smaller: the attribute call is a driver round trip, and the launch paths would make it per launch.
+inline hipError_t odamd_ensure_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    struct Slot { const void* k; int dev; size_t bytes; };
+    static std::mutex mu;
+    static Slot slots[1024];
+    static int n = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> guard(mu);
+    for (int i = 0; i < n; ++i)
+        if (slots[i].k == kernel && slots[i].dev == dev) {
+            if (slots[i].bytes >= bytes) return hipSuccess;
+            e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e == hipSuccess) slots[i].bytes = bytes;
+            return e;
+        }
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && n < 1024) slots[n++] = {kernel, dev, bytes};
+    return e;
+}
+
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = one 16-byte MFMA fragment
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;

@@ -1390,7 +1390,7 @@ int launch_stream(const ConvP& c, hipStream_t st) {
 #define ODAMD_STREAM(NPF)                                                                                        \
     {                                                                                                            \
         auto k = conv1x1_stream_kernel<DT, CG, WP, WC, NPF>;                                                     \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        (void)odamd_ensure_lds((const void*)k, lds);                                                            \
         k<<<grid, 256, lds, st>>>(p);                                                                            \
     }
     if (parts <= 8) ODAMD_STREAM(4)
@@ -1514,7 +1514,7 @@ int launch_dma(const ConvP& c, hipStream_t st) {
     if (lds > LDS_MAX) return ODAMD_E_SHAPE;
     if (p.npad > ((dma_max_in_pix(KS, PG, ST) + 63) & ~63)) return ODAMD_E_SHAPE;
     auto k = conv_dma_kernel<KS, PG, CG, WP, WC, CKB, NBUF, ST>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)odamd_ensure_lds((const void*)k, lds);
     k<<<p.nblocks, 64 * NW, lds, st>>>(p);
     return (int)hipGetLastError();
 }
@@ -1747,8 +1747,7 @@ int launch_mp(const odamd_conv_desc* a, const odamd_conv_desc* b, hipStream_t st
     p.w1_off = p.w2_off + (int)(32 * CG2 * rsb);
     const size_t lds = p.w1_off + 32 * CG1 * rsb;
     auto k = conv_mp_kernel<CG2, CG1, NPF>;
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return (int)hipGetLastError();
+    if (odamd_ensure_lds((const void*)k, lds) != hipSuccess) return (int)hipGetLastError();
     int grid = lds <= 80 * 1024 ? 512 : 256;
     if (grid > p.ntiles) grid = p.ntiles;
     k<<<grid, 256, lds, st>>>(p);

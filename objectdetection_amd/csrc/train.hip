@@ -1250,7 +1250,7 @@ void wgrad_launch(const WgradPlan& o, hipStream_t st) {
 #define ODAMD_WG(WCO, WCI, R)                                                                                     \
     case WCO * 100 + WCI * 10 + R: {                                                                              \
         auto k = conv_wgrad_bf16_kernel<KS, ST, WCO, WCI, R, DT == ODAMD_DTYPE_F32>;                               \
-        if (o.lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o.lds); \
+        (void)odamd_ensure_lds((const void*)k, o.lds);                                                            \
         k<<<o.grid, 256, o.lds, st>>>(o.p);                                                                       \
         break;                                                                                                    \
     }
