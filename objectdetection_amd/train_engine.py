@@ -214,6 +214,11 @@ def detection_loss(pred, screen_list, label_expend, label_smooth):
 class TrainPlan:
     """Forward (train mode) + backward launch lists for one (batch, size, dtype)."""
 
+    # Switches for tests, which compare the results of both settings: first data-gradient writer stores (else every
+    # writer adds into zero-filled buffers); packed-weight kernels where one applies (else plain weights everywhere).
+    STORE_FIRST = True
+    PACKED_WEIGHTS = True
+
     def __init__(self, model, state, batch, size, dtype=F32, block_input=None):
         """`model`: a yolov7 mirror (whole network incl. decode), or any block when `block_input`
         = (channels, height, width) is given (NCHW float32 in, NCHW float32 out; used by tests)."""
@@ -266,6 +271,8 @@ class TrainPlan:
         # Gradient buffers whose first writer of the backward pass stores (instead of adding) need no zero fill; the
         # others come first in the pool and are cleared once per step.
         self.dgrad_stores, need_zero = self._gradient_write_modes()
+        if not self.STORE_FIRST:
+            self.dgrad_stores, need_zero = set(), set(range(len(self.bufs)))
         order = sorted(range(len(self.bufs)), key=lambda i: (i not in need_zero, i))
         self.gbufs, o = [None] * len(self.bufs), 0
         for i in order:
@@ -397,7 +404,7 @@ class TrainPlan:
         packed weights where one of them serves the launch (bf16; they apply scale and shift, here 1 and 0), else the
         plain [rows][row_len] order.  Returns (tensor, PackDesc fragment code)."""
         frag = 0
-        if self.dtype == BF16 and not d.in_upzero2 and not d.accumulate:
+        if self.PACKED_WEIGHTS and self.dtype == BF16 and not d.in_upzero2 and not d.accumulate:
             if getattr(self, '_unit', None) is None:
                 self._unit = (torch.ones(4096, dtype=torch.float32, device=self.dev),
                               torch.zeros(4096, dtype=torch.float32, device=self.dev))

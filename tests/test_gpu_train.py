@@ -335,6 +335,62 @@ def test_conv_wgrad_dtypes(cin, cout, k, s, h, w, b, dtype):
     assert float((dw.cpu().double() - ref).abs().max()) <= 4e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('cin,cout,k,s,h,w,b', [
+    (64, 64, 1, 1, 80, 80, 8), (128, 128, 1, 1, 37, 53, 3), (32, 32, 3, 1, 160, 160, 2), (16, 32, 3, 2, 128, 128, 4),
+    (3, 16, 3, 1, 96, 96, 4), (64, 64, 3, 2, 80, 80, 4), (256, 256, 1, 1, 40, 40, 8)])
+def test_conv_wgrad_many_patches(cin, cout, k, s, h, w, b, dtype):
+    """Shapes where a workgroup walks several patches (next patch's loads in flight during the matrix work), the
+    flat pixel list of a 1x1 layer ends in a ragged patch, and the split count is chosen by the cost estimate."""
+    test_conv_wgrad_dtypes(cin, cout, k, s, h, w, b, dtype)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('kind,kw,shape', [
+    ('elan', dict(in_=32, out_=64, n=2), (2, 32, 16, 16)),
+    ('mp', dict(in_=32, out_=64), (2, 32, 16, 16)),
+    ('sppcspc', dict(in_=64, out_=32), (2, 64, 20, 20)),
+    ('elan_h', dict(in_=256, out_=128), (4, 256, 20, 20))])
+def test_backward_write_modes_and_weight_layouts_agree(te, kind, kw, shape, dtype):
+    """The first data-gradient launch that writes a gradient range stores instead of adding into a zero-filled
+    buffer, and bf16 launches read fragment-ordered weight copies on the packed-weight kernels where one applies:
+    both are choices of the plan, not of the arithmetic.  Store-first against add-everywhere is bit-identical;
+    packed against plain kernels agrees to bf16 rounding of the stored tensors."""
+    from objectdetection_amd.model import layer
+    from objectdetection_amd.engine import BF16, F32
+    torch.manual_seed(31)
+    mod = getattr(layer, kind)(**kw).cuda().train()
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(shape, generator=g).cuda()
+    results = []
+    for store_first, packed in ((True, True), (False, True), (True, False)):
+        te.TrainPlan.STORE_FIRST, te.TrainPlan.PACKED_WEIGHTS = store_first, packed
+        try:
+            state = te.FlatState(mod)
+            plan = te.TrainPlan(mod, state, shape[0], shape[2], dtype=BF16 if dtype == 'bf16' else F32, block_input=shape[1:])
+        finally:
+            te.TrainPlan.STORE_FIRST, te.TrainPlan.PACKED_WEIGHTS = True, True
+        y = plan.forward(x).clone()
+        if not results:
+            gy = torch.randn(y.shape, generator=g).cuda()
+        plan.gout_nchw.copy_(gy)
+        state.grad.zero_()
+        plan.backward(x)
+        torch.cuda.synchronize()
+        results.append([y.cpu(), plan.dx_nchw.cpu().clone(), state.grad.cpu().clone()])
+    base, added, plain = results
+    # the float32 backward of the stride-1 max pools adds with float atomics: repeatable to rounding only
+    exact = not (kind == 'sppcspc' and dtype == 'f32')
+    for name, a, b2 in zip(('y', 'dx', 'grad'), base, added):
+        if exact:
+            assert torch.equal(a, b2), (name, int((a != b2).sum()), float((a - b2).abs().max()), float(a.abs().max()))
+        else:
+            assert float((a - b2).abs().max()) <= 1e-5 * float(a.abs().max()), name
+    for a, b2 in zip(base, plain):
+        scale = float(a.abs().max()) + 1e-30
+        assert float((a - b2).abs().max()) <= (2e-2 if dtype == 'bf16' else (0.0 if exact else 1e-5)) * scale
+
+
 def _oracle_block_train(kind, mod, x, gy, act_bf16=False):
     """float32 CPU autograd of one block in train mode: output, dx, parameter gradients.  act_bf16: block
     activations rounded to bf16 (what the bf16 path pools), gradients straight through."""
