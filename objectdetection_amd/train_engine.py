@@ -660,9 +660,16 @@ class TrainPlan:
         stream = _stream()
         if self.grad_zero is not None:
             self.grad_zero.zero_()
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        side_busy = False
         if not self.block:
-            check(lib.odamd_nchw_to_nhwc(image.data_ptr(), self.image8.data_ptr(), self.batch, 3, self.size, self.size, 3,
-                                         8, self.dtype, stream), 'image_to_nhwc')
+            # the NHWC copy of the image is read by the first layer's weight gradient only (last launch of the second stream)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                check(lib.odamd_nchw_to_nhwc(image.data_ptr(), self.image8.data_ptr(), self.batch, 3, self.size, self.size, 3,
+                                             8, self.dtype, _stream()), 'image_to_nhwc')
+            side_busy = True
             arr = (C.c_void_p * 3)(*[g.data_ptr() for g in self.dheads])
             check(lib.odamd_decode_backward(C.byref(self.decode_desc), self.dpred.data_ptr(), C.byref(arr), stream),
                   'decode_backward')
@@ -672,9 +679,6 @@ class TrainPlan:
         # The weight gradients are off the critical path (layer L's data gradient and layer L-1's BatchNorm backward do
         # not read them): they run on a second stream, one after the other, each behind an event recorded after the
         # BatchNorm backward that produced its dY.  Small layers do not fill the chip, so the two streams overlap.
-        main = torch.cuda.current_stream()
-        side = self._side_stream()
-        side_busy = False
         for i, (fn, args, name, extra) in enumerate(self.bwd):
             if fn == 'bn_bwd':
                 self._bn_bwd(*args, stream)
