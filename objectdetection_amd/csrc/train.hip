@@ -594,7 +594,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             if (i >= total) continue;
             int valid;
             const char* src;
-            if (i < nd) {
+            if constexpr (KS == 1) {
+                // one row of pixels (see wgrad_plan): patch t starts at pixel t * TW, no halo
+                const bool isd = i < nd;
+                const int k = isd ? i : i - nd;
+                const int pix = isd ? k / PCO : k / PCI, part = isd ? k % PCO : k % PCI;
+                const unsigned q = (unsigned)(t * p.TW + pix);
+                valid = q < (unsigned)p.Wo ? (isd ? nco : nci) - part * EPP : 0;
+                src = (isd ? (const char*)p.dy : (const char*)p.x) +
+                      ((size_t)q * (unsigned)(isd ? p.dy_ld : p.x_ld) + (unsigned)((isd ? co0 : ci0) + part * EPP)) * GES;
+            } else if (i < nd) {
                 const int pix = i / PCO, part = i % PCO;
                 const int ty = div_small_t(pix, p.inv_tw), tx = pix - ty * p.TW;
                 const int oy = oy0 + ty, ox = ox0 + tx;
