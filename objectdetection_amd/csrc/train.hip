@@ -515,6 +515,17 @@ __device__ __forceinline__ void split_store(float4 v, uint16_t* hi, uint16_t* lo
     *(uint2*)lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
 }
 
+// c ? a : b by bit masks: a select between two values that live in registers, where the compiler would otherwise
+// put the pair into a private-memory table and index it with c
+__device__ __forceinline__ unsigned pick_u32(bool c, unsigned a, unsigned b) {
+    const unsigned m = 0u - (unsigned)c;
+    return (a & m) | (b & ~m);
+}
+__device__ __forceinline__ const char* pick_ptr(bool c, const char* a, const char* b) {
+    const unsigned long long m = 0ull - (unsigned long long)c;
+    return (const char*)(((unsigned long long)a & m) | ((unsigned long long)b & ~m));
+}
+
 // 16-byte pieces per thread that one staging batch of the weight-gradient kernel holds in registers
 __host__ __device__ constexpr int wgrad_batch(int ks, bool split) { return split ? 6 : (ks == 3 ? 9 : 12); }
 __device__ __forceinline__ int div_small_t(int v, float inv) { return (int)(((float)v + 0.5f) * inv); }   // exact for v < 2^21, divisor < 2^12
@@ -580,7 +591,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     const bool single = total <= 256 * NB;
     uint4 v[NB];
-    auto load_batch = [&](int t, int b0) {
+    auto load_batch = [&](int t, int b0) __attribute__((always_inline)) {
         const int b = t / (p.tiles_x * p.tiles_y), tt = t % (p.tiles_x * p.tiles_y);
         const int oy0 = (tt / p.tiles_x) * p.TH, ox0 = (tt % p.tiles_x) * p.TW;
         const int iy0 = oy0 * ST - PAD, ix0 = ox0 * ST - PAD;
@@ -601,8 +612,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const int pix = isd ? k / PCO : k / PCI, part = isd ? k % PCO : k % PCI;
                 const unsigned q = (unsigned)(t * p.TW + pix);
                 valid = q < (unsigned)p.Wo ? (isd ? nco : nci) - part * EPP : 0;
-                src = (isd ? (const char*)p.dy : (const char*)p.x) +
-                      ((size_t)q * (unsigned)(isd ? p.dy_ld : p.x_ld) + (unsigned)((isd ? co0 : ci0) + part * EPP)) * GES;
+                src = pick_ptr(isd, (const char*)p.dy, (const char*)p.x) +
+                      ((size_t)q * pick_u32(isd, (unsigned)p.dy_ld, (unsigned)p.x_ld) + pick_u32(isd, (unsigned)co0, (unsigned)ci0) + (unsigned)(part * EPP)) * GES;
             } else if (i < nd) {
                 const int pix = i / PCO, part = i % PCO;
                 const int ty = div_small_t(pix, p.inv_tw), tx = pix - ty * p.TW;
@@ -630,7 +641,53 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
     };
-    auto store_batch = [&](int b0) {
+    // 1x1 layers with single-batch patches: the element offset of a piece from the patch's first pixel does not depend
+    // on the patch and is kept; the patch adds a uniform offset and the row-end test.  (Selections between two fields of
+    // `p` by a lane-dependent condition would make the compiler keep `p` in private memory: copies first.)
+    const unsigned dy_ld = (unsigned)p.dy_ld, x_ld = (unsigned)p.x_ld;
+    const char* const dy_base = (const char*)p.dy;
+    const char* const x_base = (const char*)p.x;
+    const bool ragged = (nco % EPP) != 0 || (nci % EPP) != 0;      // workgroup-uniform: a channel tile ends inside a 16-byte piece
+    unsigned flat_off[KS == 1 ? NB : 1];
+    if constexpr (KS == 1) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int i = tid + j * 256;
+            const bool isd = i < nd;
+            const int k = isd ? i : i - nd;
+            const int pix = isd ? k / PCO : k / PCI, part = isd ? k % PCO : k % PCI;
+            flat_off[j] = (unsigned)pix * pick_u32(isd, dy_ld, x_ld) + pick_u32(isd, (unsigned)co0, (unsigned)ci0) + (unsigned)(part * EPP);
+        }
+    }
+    auto load_flat = [&](int t) __attribute__((always_inline)) {
+        if constexpr (KS == 1) {
+            const int q0 = t * p.TW, lim = p.Wo - q0;                  // uniform
+            const unsigned ody = (unsigned)q0 * dy_ld, ox = (unsigned)q0 * x_ld;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                int i = tid + j * 256;
+                asm volatile("" : "+v"(i));
+                const bool isd = i < nd;
+                const int k = isd ? i : i - nd;
+                const int pix = isd ? k / PCO : k / PCI, part = isd ? k % PCO : k % PCI;
+                const int valid = (i < total && pix < lim) ? (int)pick_u32(isd, (unsigned)nco, (unsigned)nci) - part * EPP : 0;
+                v[j] = make_uint4(0u, 0u, 0u, 0u);
+                if (valid > 0) {
+                    v[j] = *(const uint4*)(pick_ptr(isd, dy_base, x_base) + ((size_t)pick_u32(isd, ody, ox) + flat_off[j]) * GES);
+                    if (ragged && valid < EPP) {
+                        if constexpr (SPLIT) {
+                            if (valid < 2) v[j].y = 0u;
+                            if (valid < 3) v[j].z = 0u;
+                            v[j].w = 0u;
+                        } else {
+                            v[j] = mask_bf16x8(v[j], valid);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    auto store_batch = [&](int b0) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             int i = b0 + tid + j * 256;
@@ -648,7 +705,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
     };
-    if (single && split < p.ntiles) load_batch(split, 0);
+    auto prefetch = [&](int t) __attribute__((always_inline)) {
+        if constexpr (KS == 1) load_flat(t);
+        else load_batch(t, 0);
+    };
+    if (single && split < p.ntiles) prefetch(split);
     for (int t = split; t < p.ntiles; t += p.nsplit) {
         __syncthreads();                                   // the previous patch has been consumed
         if (single) {
@@ -657,7 +718,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int b0 = 0; b0 < total; b0 += 256 * NB) { load_batch(t, b0); store_batch(b0); }
         }
         __syncthreads();
-        if (single && t + p.nsplit < p.ntiles) load_batch(t + p.nsplit, 0);
+        if (single && t + p.nsplit < p.ntiles) prefetch(t + p.nsplit);
         for (int s = s0; s < s1; ++s) {
             const int qa = 16 * s + 8 * kk + trq;                    // this lane's row of the first block; the second is 4 further
             const int t0 = tab[qa], t1 = tab[qa + 4];
@@ -777,7 +838,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_first_kernel(WgradP p) {
     const bool single = total <= 256 * NB;
     for (int i = tid; i < (npix - nreal) * PPP; i += 256) *(uint4*)(dyl + (size_t)nreal * 32 * ES + i * 16) = make_uint4(0u, 0u, 0u, 0u);
     uint4 v[NB];
-    auto load_batch = [&](int t, int b0) {
+    auto load_batch = [&](int t, int b0) __attribute__((always_inline)) {
         const int b = t / (p.tiles_x * p.tiles_y), tt = t % (p.tiles_x * p.tiles_y);
         const int oy0 = (tt / p.tiles_x) * p.TH, ox0 = (tt % p.tiles_x) * p.TW;
 #pragma unroll
@@ -812,7 +873,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_first_kernel(WgradP p) {
             }
         }
     };
-    auto store_batch = [&](int b0) {
+    auto store_batch = [&](int b0) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             int i = b0 + tid + j * 256;
@@ -1426,6 +1487,8 @@ int odamd_conv_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* 
     const int rc = wgrad_plan(batch, h, w, cin, cout, ksize, stride, dtype, o);
     if (rc != ODAMD_OK) return rc;
     if (workspace_bytes < (size_t)o.nslices * o.p.slice * sizeof(float)) return ODAMD_E_WORKSPACE;
+    // the 1x1 kernels form element offsets inside the whole flat pixel row in 32 bits
+    if (ksize == 1 && ((size_t)o.p.W * (size_t)x_ld >= ((size_t)1 << 32) || (size_t)o.p.Wo * (size_t)dy_ld >= ((size_t)1 << 32))) return ODAMD_E_SHAPE;
     o.p.x = x; o.p.dy = dy; o.p.part = (float*)workspace;
     o.p.x_ld = x_ld; o.p.dy_ld = dy_ld;
     hipStream_t st = (hipStream_t)stream;
