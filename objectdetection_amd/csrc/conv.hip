@@ -178,7 +178,9 @@ __device__ __forceinline__ void nhwc_epilogue(const f32x16_t (&acc)[PGW][CGW], c
 // Stores go through a buffer resource: lanes whose pixel lies outside the image get offset 0xFFFFFFFF,
 // which the range check of the resource drops, so no lane mask is needed.
 // `ytensor`: the address the pixel indices in `opix` (+ ybase) are relative to; `ybytes`: bytes addressable from it.
-template <int DT, int PGW, int CGW, bool ACT>
+// ACCUM: the results are added to what the destination holds (one 16-byte read per store; a position outside the
+// resource reads zero and its store is dropped); each element has exactly one writer, so no atomics.
+template <int DT, int PGW, int CGW, bool ACT, bool ACCUM = false>
 __device__ __forceinline__ void nhwc_epilogue_fast(const f32x16_t (&acc)[PGW][CGW], const int (&opix)[PGW], char* stage, int lane,
                                                    int cw0, int ybase, const Affine<DT, CGW>& aff, char* ytensor,
                                                    unsigned ybytes, int y_ld) {
@@ -217,6 +219,21 @@ __device__ __forceinline__ void nhwc_epilogue_fast(const f32x16_t (&acc)[PGW][CG
 #pragma unroll
                 for (int e = 0; e < CPL; ++e) v[e] = silu<DT>(v[e]);
             }
+            const int voff = op >= 0 ? ((ybase + op) * y_ld + c_lane) * ES : -1;
+            if constexpr (ACCUM) {
+                const u32x4 old = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+                if constexpr (DT == ODAMD_DTYPE_F32) {
+                    v[0] += __uint_as_float(old.x); v[1] += __uint_as_float(old.y);
+                    v[2] += __uint_as_float(old.z); v[3] += __uint_as_float(old.w);
+                } else {
+                    const uint32_t w[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[(2 * e) % CPL] += __uint_as_float(w[e] << 16);
+                        v[(2 * e + 1) % CPL] += __uint_as_float(w[e] & 0xFFFF0000u);
+                    }
+                }
+            }
             u32x4 pk;
             if constexpr (DT == ODAMD_DTYPE_F32) {
                 pk = u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
@@ -226,7 +243,6 @@ __device__ __forceinline__ void nhwc_epilogue_fast(const f32x16_t (&acc)[PGW][CG
                 pk.z = f32x2_to_bf16x2(v[4 % CPL], v[5 % CPL]);
                 pk.w = f32x2_to_bf16x2(v[6 % CPL], v[7 % CPL]);
             }
-            const int voff = op >= 0 ? ((ybase + op) * y_ld + c_lane) * ES : -1;
             __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, voff, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
@@ -235,7 +251,8 @@ __device__ __forceinline__ void nhwc_epilogue_fast(const f32x16_t (&acc)[PGW][CG
 
 // Host side: may the branch-free epilogue serve this output?  (whole channel blocks, 32-bit byte offsets)
 static inline bool fast_epilogue_ok(size_t npix, int y_ld, int es, int Cout, int block_channels, int accum) {
-    return !accum && Cout % block_channels == 0 && npix * (size_t)y_ld * es < ((size_t)1 << 31);
+    (void)accum;      // the fast epilogue has an adding form
+    return Cout % block_channels == 0 && npix * (size_t)y_ld * es < ((size_t)1 << 31);
 }
 
 struct ConvP {
@@ -507,7 +524,8 @@ __global__ void __launch_bounds__(256, UPSKIP ? (DT == ODAMD_DTYPE_BF16 ? 3 : 2)
     char* stage = lds + wave * (32 * (CGW * 128 + 16));
     if (p.fast_epi) {
         if (cw0 >= p.Cout) return;
-        if (p.act) nhwc_epilogue_fast<DT, PGW, CGW, true>(acc, opix, stage, lane, cw0, b * p.Ho * p.Wo, aff, p.y, p.ybytes, p.y_ld);
+        if (p.accum && !p.act) nhwc_epilogue_fast<DT, PGW, CGW, false, true>(acc, opix, stage, lane, cw0, b * p.Ho * p.Wo, aff, p.y, p.ybytes, p.y_ld);
+        else if (p.act) nhwc_epilogue_fast<DT, PGW, CGW, true>(acc, opix, stage, lane, cw0, b * p.Ho * p.Wo, aff, p.y, p.ybytes, p.y_ld);
         else nhwc_epilogue_fast<DT, PGW, CGW, false>(acc, opix, stage, lane, cw0, b * p.Ho * p.Wo, aff, p.y, p.ybytes, p.y_ld);
         return;
     }
@@ -647,7 +665,8 @@ __global__ void __launch_bounds__(256) conv1x1_stream_kernel(StreamP p) {
         const int cw0 = co0 + wc * CGW * 32;
         if (p.fast_epi) {
             if (cw0 < p.Cout) {
-                if (p.act) nhwc_epilogue_fast<DT, PGW, CGW, true>(acc, opix, stage, lane, cw0, 0, aff, p.y, p.ybytes, p.y_ld);
+                if (p.accum && !p.act) nhwc_epilogue_fast<DT, PGW, CGW, false, true>(acc, opix, stage, lane, cw0, 0, aff, p.y, p.ybytes, p.y_ld);
+                else if (p.act) nhwc_epilogue_fast<DT, PGW, CGW, true>(acc, opix, stage, lane, cw0, 0, aff, p.y, p.ybytes, p.y_ld);
                 else nhwc_epilogue_fast<DT, PGW, CGW, false>(acc, opix, stage, lane, cw0, 0, aff, p.y, p.ybytes, p.y_ld);
             }
         } else {
@@ -1343,7 +1362,7 @@ int launch_conv(ConvP p, hipStream_t st) {
     p.nblocks = p.B * p.tiles_x * p.tiles_y * p.ncb;
     {
         const size_t npix = (size_t)p.B * p.Ho * p.Wo;
-        p.fast_epi = !p.nchw && fast_epilogue_ok(npix, p.y_ld, ES, p.Cout, 32 * (CG / WC), p.accum);
+        p.fast_epi = !p.nchw && !(p.accum && p.act) && fast_epilogue_ok(npix, p.y_ld, ES, p.Cout, 32 * (CG / WC), p.accum);
         p.ybytes = p.fast_epi ? (unsigned)((npix - 1) * p.y_ld * ES + (size_t)p.Cout * ES) : 0u;
     }
     size_t lds = (((size_t)p.IH * p.IW * PS + 255) & ~(size_t)255) + w_bytes;
@@ -1373,7 +1392,7 @@ int launch_stream(const ConvP& c, hipStream_t st) {
     p.x = c.x; p.w = c.w; p.scale = c.scale; p.shift = c.shift; p.y = c.y;
     p.npix = c.B * c.H * c.W; p.Cin = c.Cin; p.Cout = c.Cout; p.x_ld = c.x_ld; p.y_ld = c.y_ld;
     p.ntiles = (p.npix + 127) / 128; p.act = c.act; p.accum = c.accum;
-    p.fast_epi = fast_epilogue_ok((size_t)p.npix, p.y_ld, ES, p.Cout, 32 * (CG / WC), p.accum);
+    p.fast_epi = !(p.accum && p.act) && fast_epilogue_ok((size_t)p.npix, p.y_ld, ES, p.Cout, 32 * (CG / WC), p.accum);
     p.ybytes = p.fast_epi ? (unsigned)(((size_t)p.npix - 1) * p.y_ld * ES + (size_t)p.Cout * ES) : 0u;
     const int cbytes = c.Cin * ES, rsb = cbytes + 16;
     const size_t epi = (size_t)4 * 32 * ((CG / WC) * 128 + 16);

@@ -798,7 +798,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // full.  x is the NHWC image padded to 8 channels.  Four waves split the pixels of a patch; slices and
 // fold as in the general kernels.
 template <int DT>
-__global__ void __launch_bounds__(256) conv_wgrad_first_kernel(WgradP p) {
+__global__ void __launch_bounds__(256, 5) conv_wgrad_first_kernel(WgradP p) {
     constexpr int ES = DT == ODAMD_DTYPE_F32 ? 4 : 2;
     constexpr int KSTEP = DT == ODAMD_DTYPE_F32 ? 2 : 16;   // pixels per MFMA
     constexpr int KL = KSTEP / 2;                            // pixels per lane half
