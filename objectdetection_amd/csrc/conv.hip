@@ -183,7 +183,7 @@ __device__ __forceinline__ void nhwc_epilogue(const f32x16_t (&acc)[PGW][CGW], c
 template <int DT, int PGW, int CGW, bool ACT, bool ACCUM = false>
 __device__ __forceinline__ void nhwc_epilogue_fast(const f32x16_t (&acc)[PGW][CGW], const int (&opix)[PGW], char* stage, int lane,
                                                    int cw0, int ybase, const Affine<DT, CGW>& aff, char* ytensor,
-                                                   unsigned ybytes, int y_ld) {
+                                                   unsigned ybytes, int y_ld, int c_end = 0x7fffffff) {
     constexpr int ES = Elem<DT>::SIZE;
     const int r = lane & 31, h = lane >> 5;
     constexpr int CPL = 16 / ES;
@@ -193,6 +193,7 @@ __device__ __forceinline__ void nhwc_epilogue_fast(const f32x16_t (&acc)[PGW][CG
     constexpr int RPP = 64 / LPR;
     const int part = lane % LPR;
     const int c_lane = cw0 + part * CPL;
+    const bool c_ok = c_lane + CPL <= c_end;       // c_end: first channel that does not exist (whole 16-byte pieces before it)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ytensor, 0, ybytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < PGW; ++i) {
@@ -219,7 +220,7 @@ __device__ __forceinline__ void nhwc_epilogue_fast(const f32x16_t (&acc)[PGW][CG
 #pragma unroll
                 for (int e = 0; e < CPL; ++e) v[e] = silu<DT>(v[e]);
             }
-            const int voff = op >= 0 ? ((ybase + op) * y_ld + c_lane) * ES : -1;
+            const int voff = (op >= 0 && c_ok) ? ((ybase + op) * y_ld + c_lane) * ES : -1;
             if constexpr (ACCUM) {
                 const u32x4 old = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
                 if constexpr (DT == ODAMD_DTYPE_F32) {
@@ -524,9 +525,9 @@ __global__ void __launch_bounds__(256, UPSKIP ? (DT == ODAMD_DTYPE_BF16 ? 3 : 2)
     char* stage = lds + wave * (32 * (CGW * 128 + 16));
     if (p.fast_epi) {
         if (cw0 >= p.Cout) return;
-        if (p.accum && !p.act) nhwc_epilogue_fast<DT, PGW, CGW, false, true>(acc, opix, stage, lane, cw0, b * p.Ho * p.Wo, aff, p.y, p.ybytes, p.y_ld);
-        else if (p.act) nhwc_epilogue_fast<DT, PGW, CGW, true>(acc, opix, stage, lane, cw0, b * p.Ho * p.Wo, aff, p.y, p.ybytes, p.y_ld);
-        else nhwc_epilogue_fast<DT, PGW, CGW, false>(acc, opix, stage, lane, cw0, b * p.Ho * p.Wo, aff, p.y, p.ybytes, p.y_ld);
+        if (p.accum && !p.act) nhwc_epilogue_fast<DT, PGW, CGW, false, true>(acc, opix, stage, lane, cw0, b * p.Ho * p.Wo, aff, p.y, p.ybytes, p.y_ld, p.Cout);
+        else if (p.act) nhwc_epilogue_fast<DT, PGW, CGW, true>(acc, opix, stage, lane, cw0, b * p.Ho * p.Wo, aff, p.y, p.ybytes, p.y_ld, p.Cout);
+        else nhwc_epilogue_fast<DT, PGW, CGW, false>(acc, opix, stage, lane, cw0, b * p.Ho * p.Wo, aff, p.y, p.ybytes, p.y_ld, p.Cout);
         return;
     }
     nhwc_epilogue<DT, PGW, CGW>(acc, opix, stage, lane, cw0, (size_t)b * p.Ho * p.Wo, aff, p.Cout, p.y, p.y_ld, p.act, p.accum);
@@ -1362,7 +1363,8 @@ int launch_conv(ConvP p, hipStream_t st) {
     p.nblocks = p.B * p.tiles_x * p.tiles_y * p.ncb;
     {
         const size_t npix = (size_t)p.B * p.Ho * p.Wo;
-        p.fast_epi = !p.nchw && !(p.accum && p.act) && fast_epilogue_ok(npix, p.y_ld, ES, p.Cout, 32 * (CG / WC), p.accum);
+        // this kernel masks the lanes past the last channel, so whole 16-byte pieces are enough
+        p.fast_epi = !p.nchw && !(p.accum && p.act) && fast_epilogue_ok(npix, p.y_ld, ES, p.Cout, 16 / ES, p.accum);
         p.ybytes = p.fast_epi ? (unsigned)((npix - 1) * p.y_ld * ES + (size_t)p.Cout * ES) : 0u;
     }
     size_t lds = (((size_t)p.IH * p.IW * PS + 255) & ~(size_t)255) + w_bytes;
