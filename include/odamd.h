@@ -32,7 +32,7 @@ extern "C" {
 #define ODAMD_DTYPE_F32 0
 #define ODAMD_DTYPE_BF16 1
 
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header (3); bumped on any change of a signature or of a structure the caller fills. */
 int odamd_abi_version(void);
 /* Human-readable text for a return code (static storage). */
 const char* odamd_error_string(int code);

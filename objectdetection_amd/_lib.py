@@ -13,7 +13,7 @@ import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libodamd.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(f'{LIB_PATH} not found: build it with `make -C objectdetection_amd/csrc` '

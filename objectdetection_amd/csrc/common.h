@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define ODAMD_ABI_VERSION 2
+#define ODAMD_ABI_VERSION 3
 
 #include <mutex>
 // Raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) on the current device only when the
