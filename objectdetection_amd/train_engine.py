@@ -186,6 +186,54 @@ def _pack_positives(screen_list, label_expend, dev):
     return n_pos, screen.data_ptr(), simg.data_ptr(), label.data_ptr(), (screen, simg, label)
 
 
+class _PositiveStager:
+    """_pack_positives without a host-device synchronisation: the three arrays go through page-locked staging
+    buffers (two slots, used in turn; a slot is reused only after the copy that read it has completed) into device
+    buffers that persist, with asynchronous copies on the current stream.  The Python thread can then enqueue the
+    backward pass while the forward pass is still running."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.slots = [None, None]
+        self.turn = 0
+
+    def _slot(self, n_pos, n_label):
+        i = self.turn
+        self.turn ^= 1
+        s = self.slots[i]
+        if s is None or s['cap'] < n_pos or s['lcap'] < n_label:
+            cap, lcap = max(1024, 2 * n_pos), max(1024, 2 * n_label)
+            s = self.slots[i] = dict(
+                cap=cap, lcap=lcap, event=None,
+                h_idx=torch.empty(2 * cap, dtype=torch.int32).pin_memory(), h_lab=torch.empty(lcap, dtype=torch.float32).pin_memory(),
+                d_idx=torch.empty(2 * cap, dtype=torch.int32, device=self.dev), d_lab=torch.empty(lcap, dtype=torch.float32, device=self.dev))
+        if s['event'] is not None:
+            s['event'].synchronize()             # the copy that read this slot two calls ago (long done)
+        return s
+
+    def pack(self, screen_list, label_expend):
+        n_pos = sum(len(t) for t in screen_list)
+        if not n_pos:
+            return 0, None, None, None, None
+        lab = label_expend.to(torch.float32).contiguous().view(-1)
+        s = self._slot(n_pos, lab.numel())
+        cap, o = s['cap'], 0
+        for b, t in enumerate(screen_list):
+            n = len(t)
+            if n:
+                s['h_idx'][o:o + n] = t
+                s['h_idx'][cap + o:cap + o + n] = b
+                o += n
+        s['h_lab'][:lab.numel()] = lab
+        s['d_idx'][:n_pos].copy_(s['h_idx'][:n_pos], non_blocking=True)
+        s['d_idx'][cap:cap + n_pos].copy_(s['h_idx'][cap:cap + n_pos], non_blocking=True)
+        s['d_lab'][:lab.numel()].copy_(s['h_lab'][:lab.numel()], non_blocking=True)
+        s['event'] = torch.cuda.Event()
+        s['event'].record()
+        es = s['d_idx'].element_size()
+        return n_pos, s['d_idx'].data_ptr(), s['d_idx'].data_ptr() + cap * es, s['d_lab'].data_ptr(), s
+
+
 def detection_loss(pred, screen_list, label_expend, label_smooth):
     """loss_class.__call__ (train_class.py:397-474) on any (B,R,K) float32 CUDA prediction, value only
     (the validation loss, train_class.py:311).  Returns a (4,) device tensor."""
@@ -648,7 +696,9 @@ class TrainPlan:
                                                self.loss_ws.data_ptr(), self.loss_ws.numel(), _stream()),
                   'detection_loss_dev')
             return self.loss_out
-        n_pos, sp, ip, lp, self._keep_loss = _pack_positives(screen_list, label_expend, dev)
+        if getattr(self, '_stager', None) is None:
+            self._stager = _PositiveStager(dev)
+        n_pos, sp, ip, lp, self._keep_loss = self._stager.pack(screen_list, label_expend)
         b, r, k = self.pred.shape
         check(lib.odamd_detection_loss(self.pred.data_ptr(), self.dpred.data_ptr(), sp, ip, lp, b, r, k, n_pos,
                                        float(label_smooth), self.loss_out.data_ptr(), self.loss_ws.data_ptr(),
