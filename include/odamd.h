@@ -279,6 +279,13 @@ int odamd_maxpool2_backward(const void* x, int x_ld, const void* dy, int dy_ld, 
                             int w, int c, int dtype, void* stream);
 int odamd_maxpool_s1_backward(const void* x, int x_ld, const void* dy, int dy_ld, void* dx, int dx_ld, int batch,
                               int h, int w, int c, int ksize, int dtype, void* stream);
+/* Backward of the three stride-1 max pools of an SPP block at once (sppcspc.MaxPool2d4 / 5 / 6 on one input,
+ * model/layer.py:186-188, :215-217, as torch.autograd differentiates them): dx += the three window gradients, each sent to the
+ * first maximum of its window in row-major order.  dy5 / dy9 / dy13: the gradients of the three pooled tensors (same
+ * leading dimension).  bf16 planes of up to 1024 pixels run as one launch, everything else as three
+ * odamd_maxpool_s1_backward launches. */
+int odamd_spp_backward(const void* x, int x_ld, const void* dy5, const void* dy9, const void* dy13, int dy_ld, void* dx,
+                       int dx_ld, int batch, int h, int w, int c, int dtype, void* stream);
 int odamd_upsample2_backward(const void* dy, int dy_ld, void* dx, int dx_ld, int batch, int h, int w, int c,
                              int dtype, void* stream);
 

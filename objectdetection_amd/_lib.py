@@ -94,6 +94,7 @@ SIGNATURES = {
     'odamd_maxpool_s1_backward': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                           c_int, c_int, c_void_p]),
     'odamd_upsample2_backward': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'odamd_spp_backward': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'odamd_conv_wgrad_workspace_bytes': (c_size_t, [c_int] * 8),
     'odamd_conv_wgrad': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_void_p, c_size_t, c_void_p]),

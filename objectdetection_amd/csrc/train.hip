@@ -429,6 +429,73 @@ maxpool_s1_bwd_bf16_kernel(const char* __restrict__ x, int x_ld, const char* __r
     }
 }
 
+// The three stride-1 max pools of an SPP block (k = 5, 9, 13 on the same input, model/layer.py:215-217) in one launch.
+// The first maximum of a window in row-major order is the leftmost maximum of the first row that holds the maximum, so
+// the search separates: pass 1 finds, per pixel and width, the leftmost maximum of its row segment (one left-to-right
+// walk over 13 elements serves the three nested widths) and keeps (value, column) packed in LDS — the values are bf16,
+// 16 bits; pass 2 walks the rows of each window top-down over those records.  54 comparisons per element instead of
+// 25 + 81 + 169; the three gradients are added to a float32 plane in LDS and dx is read and written once.
+__global__ void __launch_bounds__(256)
+spp_bwd_bf16_kernel(const char* __restrict__ x, int x_ld, const char* __restrict__ dy5, const char* __restrict__ dy9,
+                    const char* __restrict__ dy13, int dy_ld, char* __restrict__ dx, int dx_ld, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float pl[];
+    const int hw = H * W, v = blockIdx.x, b = blockIdx.y;
+    float* grad = pl;                                        // [hw][8]
+    uint16_t* val = (uint16_t*)(pl + (size_t)hw * 8);        // [hw][8] bf16 bits
+    uint32_t* rec = (uint32_t*)(val + (size_t)hw * 8);       // [3 widths][hw][8]: value bits << 16 | column
+    for (int p = threadIdx.x; p < hw; p += 256) {
+        const uint4 t = *(const uint4*)(x + (((size_t)b * hw + p) * x_ld) * 2 + v * 16);
+        *(uint4*)(val + p * 8) = t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) grad[p * 8 + e] = 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < hw * 8; i += 256) {       // pass 1: leftmost row maxima of widths 5, 9, 13
+        const int e = i & 7, p = i >> 3;
+        const int oy = p / W, ox = p - oy * W;
+        float m5 = -INFINITY, m9 = -INFINITY, m13 = -INFINITY;
+        uint32_t r5 = 0, r9 = 0, r13 = 0;
+        for (int gx = max(ox - 6, 0); gx <= min(ox + 6, W - 1); ++gx) {
+            const uint32_t bits = val[(oy * W + gx) * 8 + e];
+            const float t = __uint_as_float(bits << 16);
+            const uint32_t packed = (bits << 16) | (uint32_t)gx;
+            const int d = abs(gx - ox);
+            if (t > m13) { m13 = t; r13 = packed; }
+            if (d <= 4 && t > m9) { m9 = t; r9 = packed; }
+            if (d <= 2 && t > m5) { m5 = t; r5 = packed; }
+        }
+        rec[i] = r5; rec[hw * 8 + i] = r9; rec[2 * hw * 8 + i] = r13;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < hw * 8; i += 256) {       // pass 2: first row holding the window maximum
+        const int e = i & 7, p = i >> 3;
+        const int oy = p / W, ox = p - oy * W;
+        const size_t go = (((size_t)b * hw + p) * dy_ld) * 2 + v * 16 + e * 2;
+        const char* dys[3] = {dy5, dy9, dy13};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int rad = 2 + 2 * k;
+            float m = -INFINITY;
+            int arg = 0;
+            for (int gy = max(oy - rad, 0); gy <= min(oy + rad, H - 1); ++gy) {
+                const uint32_t r = rec[(k * hw + gy * W + ox) * 8 + e];
+                const float t = __uint_as_float(r & 0xFFFF0000u);
+                if (t > m) { m = t; arg = gy * W + (int)(r & 0xFFFFu); }
+            }
+            atomicAdd(&grad[arg * 8 + e], bf16_to_f32(*(const uint16_t*)(dys[k] + go)));
+        }
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < hw; p += 256) {
+        float t[8];
+        char* d = dx + (((size_t)b * hw + p) * dx_ld) * 2 + v * 16;
+        Vec<ODAMD_DTYPE_BF16>::load(d, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] += grad[p * 8 + e];
+        Vec<ODAMD_DTYPE_BF16>::store(d, t);
+    }
+}
+
 // nearest x2 upsample: dx(y, x) += sum of the 2x2 block of dy.
 template <int DT>
 __global__ void __launch_bounds__(256)
@@ -1452,6 +1519,30 @@ int odamd_maxpool_s1_backward(const void* x, int x_ld, const void* dy, int dy_ld
     } else {
         return ODAMD_E_ARG;
     }
+    return (int)hipGetLastError();
+}
+
+int odamd_spp_backward(const void* x, int x_ld, const void* dy5, const void* dy9, const void* dy13, int dy_ld, void* dx,
+                       int dx_ld, int batch, int h, int w, int c, int dtype, void* stream) {
+    if (!x || !dy5 || !dy9 || !dy13 || !dx || batch < 1 || h < 1 || w < 1 || c < 1) return ODAMD_E_ARG;
+    if (dtype != ODAMD_DTYPE_F32 && dtype != ODAMD_DTYPE_BF16) return ODAMD_E_ARG;
+    // LDS of the one-launch form: float32 gradient plane, bf16 values, three planes of packed row records
+    const size_t spp_lds = (size_t)h * w * 8 * (sizeof(float) + sizeof(uint16_t) + 3 * sizeof(uint32_t));
+    if (dtype == ODAMD_DTYPE_F32 || spp_lds > 64 * 1024) {
+        // float32, or planes beyond the LDS form: the three pools one after the other
+        const void* dys[3] = {dy5, dy9, dy13};
+        const int ks[3] = {5, 9, 13};
+        for (int i = 0; i < 3; ++i) {
+            const int rc = odamd_maxpool_s1_backward(x, x_ld, dys[i], dy_ld, dx, dx_ld, batch, h, w, c, ks[i], dtype, stream);
+            if (rc) return rc;
+        }
+        return ODAMD_OK;
+    }
+    if ((c & 7) || (x_ld & 7) || (dy_ld & 7) || (dx_ld & 7) || ((uintptr_t)x & 15) || ((uintptr_t)dy5 & 15) || ((uintptr_t)dy9 & 15) ||
+        ((uintptr_t)dy13 & 15) || ((uintptr_t)dx & 15))
+        return ODAMD_E_ALIGN;
+    spp_bwd_bf16_kernel<<<dim3(c / 8, batch), 256, spp_lds, (hipStream_t)stream>>>((const char*)x, x_ld, (const char*)dy5, (const char*)dy9,
+                                                                                  (const char*)dy13, dy_ld, (char*)dx, dx_ld, h, w);
     return (int)hipGetLastError();
 }
 

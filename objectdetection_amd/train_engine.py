@@ -598,10 +598,9 @@ class TrainPlan:
                              x.w, x.cphys, self.dtype], 'maxpool2_bwd', None))
             elif kind == 'spp':
                 x, ys = op['x'], op['ys']
-                for y, kk in zip(ys, (5, 9, 13)):
-                    bwd.append((lib.odamd_maxpool_s1_backward,
-                                [self._aptr(x), self._ld(x), self._gptr(y), self._ld(y), self._gptr(x), self._ld(x), B,
-                                 x.h, x.w, x.cphys, kk, self.dtype], 'spp_bwd', None))
+                bwd.append((lib.odamd_spp_backward,
+                            [self._aptr(x), self._ld(x), self._gptr(ys[0]), self._gptr(ys[1]), self._gptr(ys[2]), self._ld(ys[0]),
+                             self._gptr(x), self._ld(x), B, x.h, x.w, x.cphys, self.dtype], 'spp_bwd', None))
             elif kind == 'from_nchw':
                 y = op['y']
                 bwd.append((lib.odamd_nhwc_to_nchw,

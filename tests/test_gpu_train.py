@@ -408,6 +408,37 @@ def _oracle_block_train(kind, mod, x, gy, act_bf16=False):
     return y.detach(), xr.grad, {k[1:]: v.grad for k, v in sd.items() if v.requires_grad}
 
 
+@pytest.mark.parametrize('h,w,c', [(20, 20, 16), (13, 17, 8), (32, 32, 24)])
+def test_spp_backward_fused_with_ties(h, w, c):
+    """odamd_spp_backward (bf16: one launch for the k = 5, 9, 13 pools of model/layer.py:215-217) on coarsely quantised
+    inputs with ties everywhere: each window's gradient goes to its first maximum in row-major order, like torch; the
+    three contributions are summed in float32 and rounded to bf16 once."""
+    from objectdetection_amd._lib import lib, check
+    g = torch.Generator().manual_seed(9)
+    b = 3
+    x = (torch.randn(b, c, h, w, generator=g) * 2).round() / 2
+    xr = x.clone().requires_grad_(True)
+    gys, total = [], 0
+    for k in (5, 9, 13):
+        y = torch.nn.functional.max_pool2d(xr, k, 1, k // 2)
+        gy = (torch.randn(y.shape, generator=g) * 4).round() / 4
+        total = total + (y * gy).sum()
+        gys.append(gy)
+    total.backward()
+    xg = x.permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
+    gyg = torch.cat([t.permute(0, 2, 3, 1) for t in gys], dim=3).contiguous().bfloat16().cuda()      # three slices of one buffer
+    base = (torch.randn(b, h, w, c, generator=g)).bfloat16().cuda()
+    dx = base.clone()
+    p0 = gyg.data_ptr()
+    check(lib.odamd_spp_backward(xg.data_ptr(), c, p0, p0 + 2 * c, p0 + 4 * c, 3 * c, dx.data_ptr(), c, b, h, w, c, 1, None))
+    torch.cuda.synchronize()
+    want = (base.float().cpu() + xr.grad.permute(0, 2, 3, 1)).bfloat16().float()
+    if h * w * 8 * 18 <= 64 * 1024:      # the one-launch form
+        assert torch.equal(dx.float().cpu(), want)
+    else:                                # three launches: dx is rounded to bf16 after each of them
+        assert float((dx.float().cpu() - want).abs().max()) <= 2.0 ** -6 * float(want.abs().max())
+
+
 @pytest.mark.parametrize('kind,kw,shape', [
     ('cbs', dict(in_=16, out_=32, kernel_size=1, stride=1), (2, 16, 16, 16)),
     ('cbs', dict(in_=32, out_=32, kernel_size=3, stride=1), (2, 32, 20, 20)),
