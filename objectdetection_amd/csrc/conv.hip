@@ -536,6 +536,87 @@ __global__ void __launch_bounds__(256, UPSKIP ? (DT == ODAMD_DTYPE_BF16 ? 3 : 2)
 #undef ODAMD_COMMIT
 
 // ------------------------------------------------------------------------------------------
+// Data gradient of a stride-2 3x3 convolution with few channels (bf16; dX of at most 32 channels, dY of 32 or 64:
+// the first two stride-2 layers of the network, whose dX maps are the largest tensors of the backward pass).
+// dX(2a + py, 2b + px) only meets the taps with ky = 1 - py (mod 2), kx = 1 - px (mod 2), which read dY(a + dr, b + dc)
+// with dr, dc in {0, 1}: a wave takes a block of 4 x 8 dY pixels, loads the four shifted copies of the block straight
+// from global memory as matrix operands (lane = pixel, 16 bytes of channels per k-step; no patch in LDS), and runs the
+// nine (class, tap) products into four accumulator tiles, one per parity class = 128 output pixels.  The flipped,
+// transposed weights ([dX channel][tap][dY channel], all taps) stay in LDS for the life of the workgroup; waves walk
+// the blocks independently (no barrier in the loop).
+// ------------------------------------------------------------------------------------------
+struct DgS2P {
+    const char* dy; const char* w; char* dx;
+    int B, Hr, Wr, dy_ld, dx_ld, Cout, accum;
+    int blocks_x, blocks_y, nblocks;
+    unsigned ybytes;
+};
+
+template <int KSTEPS>
+__global__ void __launch_bounds__(256) dgrad_s2_direct_kernel(DgS2P p) {
+    constexpr int DT = ODAMD_DTYPE_BF16;
+    constexpr int CDY = 16 * KSTEPS;                 // dY channels
+    constexpr int WRS = 9 * CDY * 2 + 16;            // LDS bytes per weight row (one dX channel)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* lds_w = lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    char* stage = lds + ((32 * WRS + 255) & ~255) + wave * (32 * (128 + 16));
+    constexpr int PPR = 9 * CDY / 8;                 // 16-byte pieces per weight row
+    for (int i = tid; i < 32 * PPR; i += 256) {
+        const int row = i / PPR, part = i - row * PPR;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (row < p.Cout) v = *(const u32x4*)(p.w + ((size_t)row * PPR + part) * 16);
+        *(u32x4*)(lds_w + row * WRS + part * 16) = v;
+    }
+    __syncthreads();
+    Affine<DT, 1> aff;
+    aff.load(nullptr, nullptr, lane, 0, p.Cout);
+    const int a_off = r * WRS + 16 * h;
+    const int Ho = 2 * p.Hr, Wo = 2 * p.Wr;
+    const int per_img = p.blocks_x * p.blocks_y;
+    for (int blk = blockIdx.x * 4 + wave; blk < p.nblocks; blk += gridDim.x * 4) {
+        const int b = blk / per_img, rem = blk - b * per_img;
+        const int by = rem / p.blocks_x, bx = rem - by * p.blocks_x;
+        const int my = by * 4 + (r >> 3), mx = bx * 8 + (r & 7);
+        u32x4 bf[2][2][KSTEPS];
+#pragma unroll
+        for (int dr = 0; dr < 2; ++dr)
+#pragma unroll
+            for (int dc = 0; dc < 2; ++dc) {
+                const bool ok = my + dr < p.Hr && mx + dc < p.Wr;
+                const char* src = p.dy + (((size_t)(b * p.Hr + my + dr) * p.Wr + mx + dc) * p.dy_ld + 8 * h) * 2;
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) bf[dr][dc][s] = ok ? *(const u32x4*)(src + s * 32) : u32x4{0u, 0u, 0u, 0u};
+            }
+        f32x16_t acc[4][1];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[c][0][e] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int py = c >> 1, px = c & 1;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                if (((py + ky) & 1) == 0 || ((px + kx) & 1) == 0) continue;      // compile time after unrolling
+                const int dr = py & (ky >> 1), dc = px & (kx >> 1);
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s)
+                    mma_step<DT>(acc[c][0], *(const u32x4*)(lds_w + a_off + (tap * CDY + 16 * s) * 2), bf[dr][dc][s]);
+            }
+        }
+        const bool inside = my < p.Hr && mx < p.Wr;
+        int opix[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) opix[c] = inside ? ((b * Ho + 2 * my + (c >> 1)) * Wo + 2 * mx + (c & 1)) : -1;
+        if (p.accum) nhwc_epilogue_fast<DT, 4, 1, false, true>(acc, opix, stage, lane, 0, 0, aff, p.dx, p.ybytes, p.dx_ld, p.Cout);
+        else nhwc_epilogue_fast<DT, 4, 1, false, false>(acc, opix, stage, lane, 0, 0, aff, p.dx, p.ybytes, p.dx_ld, p.Cout);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Streaming 1x1 convolution (stride 1, NHWC in, NHWC out; the kernel handles up to 512 bytes of input
 // channels per pixel, the dispatcher uses it up to 256, where two workgroups fit a CU).  A 1x1 convolution has no spatial structure: the pixels of the whole batch form one flat
 // list.  A persistent workgroup keeps the weight slab of its 32*CG output channels in LDS for its
@@ -1831,6 +1912,35 @@ int check_vec(const void* x, const void* y, int c, int x_ld, int y_ld, int dtype
     return ODAMD_OK;
 }
 
+// dgrad_s2_direct_kernel serves this launch: the data gradient of a stride-2 3x3 convolution (zero-upsampled input)
+// in bf16 with dY of 32 or 64 channels and dX of at most 32 (whole 16-byte pieces), plain NHWC, no affine, no activation
+bool dgrad_s2_direct_ok(const odamd_conv_desc* d, const ConvP& p) {
+    if (d->dtype != ODAMD_DTYPE_BF16 || !d->in_upzero2 || d->ksize != 3 || d->stride != 1 || d->in_pool2 || d->out_nchw_f32) return false;
+    if (d->scale || d->shift || d->act || d->w_packed) return false;
+    if ((d->cin != 32 && d->cin != 64) || d->cout > 32 || d->cout % 8 || d->x_ld % 8 || d->y_ld % 8) return false;
+    if (((uintptr_t)d->y & 15)) return false;
+    const size_t npix = (size_t)p.B * p.Ho * p.Wo;
+    return fast_epilogue_ok(npix, p.y_ld, 2, p.Cout, 8, p.accum) && npix < ((size_t)1 << 30);
+}
+
+int launch_dgrad_s2_direct(const odamd_conv_desc* d, const ConvP& c, hipStream_t st) {
+    DgS2P p = {};
+    p.dy = c.x; p.w = c.w; p.dx = c.y;
+    p.B = c.B; p.Hr = c.Hr; p.Wr = c.Wr; p.dy_ld = c.x_ld; p.dx_ld = c.y_ld; p.Cout = c.Cout; p.accum = c.accum;
+    p.blocks_x = (p.Wr + 7) / 8; p.blocks_y = (p.Hr + 3) / 4;
+    p.nblocks = p.B * p.blocks_x * p.blocks_y;
+    const size_t npix = (size_t)c.B * c.Ho * c.Wo;
+    p.ybytes = (unsigned)((npix - 1) * c.y_ld * 2 + (size_t)c.Cout * 2);
+    const int ksteps = d->cin / 16;
+    const size_t wrs = (size_t)9 * d->cin * 2 + 16;
+    const size_t lds = ((32 * wrs + 255) & ~(size_t)255) + 4 * 32 * (128 + 16);
+    int grid = (p.nblocks + 3) / 4;
+    if (grid > 1024) grid = 1024;
+    if (ksteps == 2) dgrad_s2_direct_kernel<2><<<grid, 256, lds, st>>>(p);
+    else dgrad_s2_direct_kernel<4><<<grid, 256, lds, st>>>(p);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
@@ -1904,6 +2014,7 @@ int odamd_conv_forward(const odamd_conv_desc* d, void* stream) {
         if (!g.pg) return ODAMD_E_ARG;        // this layer has no packed-weight form (odamd_conv_weight_layout returned 0)
         return dispatch_dma(p, g, st);
     }
+    if (dgrad_s2_direct_ok(d, p)) return launch_dgrad_s2_direct(d, p, st);
     return d->dtype == ODAMD_DTYPE_F32 ? dispatch_conv<ODAMD_DTYPE_F32>(p, d->ksize, d->stride, st)
                                        : dispatch_conv<ODAMD_DTYPE_BF16>(p, d->ksize, d->stride, st);
 }

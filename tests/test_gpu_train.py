@@ -515,6 +515,45 @@ def test_block_train_step_bf16(te, kind, kw, shape):
         assert not bad, (bad, max(errs.values()))
 
 
+@pytest.mark.parametrize('accum', [0, 1])
+@pytest.mark.parametrize('cdy,cdx,hr,wr,b', [(32, 16, 12, 12, 2), (64, 32, 10, 20, 2), (32, 32, 7, 13, 3), (64, 8, 5, 9, 1)])
+def test_stride2_data_gradient_direct_kernel(cdy, cdx, hr, wr, b, accum):
+    """Data gradient of a stride-2 3x3 convolution with few channels (bf16): the kernel that reads the four shifted dY
+    blocks straight from global memory against float64 conv_transpose2d, stored and added to an existing gradient, on
+    grids that are not whole 4 x 8 blocks; and against the generic kernel (forced by passing a unit scale)."""
+    import ctypes as C
+    from objectdetection_amd import _lib
+    from objectdetection_amd._lib import lib, check
+    g = torch.Generator().manual_seed(cdy * 100 + cdx + hr)
+    dy = torch.randn(b, hr, wr, cdy, generator=g).bfloat16()
+    w = (torch.randn(cdy, cdx, 3, 3, generator=g) * 0.2).bfloat16()          # forward weight (cout = cdy, cin = cdx)
+    base = torch.randn(b, 2 * hr, 2 * wr, cdx, generator=g).bfloat16()
+    ref = torch.nn.functional.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double(), stride=2, padding=1,
+                                               output_padding=1).permute(0, 2, 3, 1)
+    if accum:
+        ref = ref + base.double()
+    # data-gradient weights: [dX channel][2 - ky][2 - kx][dY channel]
+    wb = w.flip(2, 3).permute(1, 2, 3, 0).contiguous().cuda()
+    dyg = dy.cuda()
+    ones, zeros = torch.ones(64, device='cuda'), torch.zeros(64, device='cuda')
+    outs = []
+    for generic in (False, True):
+        dx = base.clone().cuda() if accum else torch.full_like(base, 7.0).cuda()
+        d = _lib.ConvDesc()
+        d.x, d.w, d.y = dyg.data_ptr(), wb.data_ptr(), dx.data_ptr()
+        d.scale, d.shift = (ones.data_ptr(), zeros.data_ptr()) if generic else (None, None)
+        d.batch, d.h, d.w_in, d.cin, d.cout = b, hr, wr, cdy, cdx
+        d.x_ld, d.y_ld, d.ksize, d.stride, d.act = cdy, cdx, 3, 1, 0
+        d.dtype, d.in_pool2, d.out_nchw_f32, d.in_upzero2, d.accumulate = 1, 0, 0, 1, accum
+        check(lib.odamd_conv_forward(C.byref(d), None))
+        torch.cuda.synchronize()
+        outs.append(dx.float().cpu().double())
+    scale = float(ref.abs().max())
+    for got in outs:
+        assert float((got - ref).abs().max()) <= 2.0 ** -7 * scale
+    assert float((outs[0] - outs[1]).abs().max()) <= 2.0 ** -7 * scale
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_pool_backward_kernels_with_ties(dtype):
     """MaxPool2d(2,2) and stride-1 MaxPool2d(k, pad k/2) backward alone, on coarsely quantised inputs
