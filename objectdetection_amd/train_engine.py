@@ -259,6 +259,66 @@ def detection_loss(pred, screen_list, label_expend, label_smooth):
     return out
 
 
+def gradient_write_modes(ops, buffer_channels):
+    """Walks the backward pass of a lowered op list symbolically.  Every activation gradient is written by the
+    data-gradient launches of the layers that consumed the activation and by the pool / upsample backward kernels, which
+    add into it.  A convolution's data gradient that is the FIRST writer of its channel range can store; afterwards
+    everything adds.  `ops`: dicts with 'kind' and Act-like 'x' / 'y' / 'ys' (buf, c0, cphys, segments);
+    `buffer_channels`: physical channel count of every buffer.  Returns (ids of the ops whose data gradient stores,
+    buffers that still need a zero fill per step: those where an adding kernel or a reader meets channels nobody
+    stored to)."""
+    written = [[False] * c for c in buffer_channels]
+    stores, need_zero = set(), set()
+
+    def span(act, off=0, n=None):
+        lo = act.c0 + off
+        return act.buf, lo, lo + (act.cphys if n is None else n)
+
+    def covered(buf, lo, hi):
+        return all(written[buf][lo:hi])
+
+    def mark(buf, lo, hi):
+        written[buf][lo:hi] = [True] * (hi - lo)
+
+    def read(act):
+        buf, lo, hi = span(act)
+        if not covered(buf, lo, hi):
+            need_zero.add(buf)
+
+    def add(act):
+        buf, lo, hi = span(act)
+        if not covered(buf, lo, hi):
+            need_zero.add(buf)
+        mark(buf, lo, hi)
+
+    for op in reversed(ops):
+        kind = op['kind']
+        if kind == 'first':
+            read(op['y'])
+        elif kind in ('conv', 'head'):
+            if kind == 'conv':
+                read(op['y'])
+            buf, lo, hi = span(op['x'])
+            if not any(written[buf][lo:hi]):
+                stores.add(id(op))
+            elif not covered(buf, lo, hi):
+                need_zero.add(buf)
+            mark(buf, lo, hi)
+        elif kind in ('maxpool2', 'upsample2'):
+            read(op['y'])
+            add(op['x'])
+        elif kind == 'spp':
+            for y in op['ys']:
+                read(y)
+                add(op['x'])
+        elif kind == 'from_nchw':
+            read(op['y'])
+        elif kind == 'to_nchw':
+            for off, n in op['x'].segments:
+                mark(*span(op['x'], off, n))
+    return stores, need_zero
+
+
 class TrainPlan:
     """Forward (train mode) + backward launch lists for one (batch, size, dtype)."""
 
@@ -480,61 +540,7 @@ class TrainPlan:
         return d
 
     def _gradient_write_modes(self):
-        """Walks the backward pass symbolically.  Every activation gradient is written by the data-gradient launches of the
-        layers that consumed the activation and by the pool / upsample backward kernels, which add into it.  A convolution's
-        data gradient that is the FIRST writer of its channel range can store; afterwards everything adds.  Returns (ids of
-        the ops whose data gradient stores, buffers that still need a zero fill per step: those where an adding kernel or a
-        reader meets channels nobody stored to)."""
-        written = [[False] * c for c, _, _ in self.pb.buffers]
-        stores, need_zero = set(), set()
-
-        def span(act, off=0, n=None):
-            lo = act.c0 + off
-            return act.buf, lo, lo + (act.cphys if n is None else n)
-
-        def covered(buf, lo, hi):
-            return all(written[buf][lo:hi])
-
-        def mark(buf, lo, hi):
-            written[buf][lo:hi] = [True] * (hi - lo)
-
-        def read(act):
-            buf, lo, hi = span(act)
-            if not covered(buf, lo, hi):
-                need_zero.add(buf)
-
-        def add(act):
-            buf, lo, hi = span(act)
-            if not covered(buf, lo, hi):
-                need_zero.add(buf)
-            mark(buf, lo, hi)
-
-        for op in reversed(self.ops):
-            kind = op['kind']
-            if kind == 'first':
-                read(op['y'])
-            elif kind in ('conv', 'head'):
-                if kind == 'conv':
-                    read(op['y'])
-                buf, lo, hi = span(op['x'])
-                if not any(written[buf][lo:hi]):
-                    stores.add(id(op))
-                elif not covered(buf, lo, hi):
-                    need_zero.add(buf)
-                mark(buf, lo, hi)
-            elif kind in ('maxpool2', 'upsample2'):
-                read(op['y'])
-                add(op['x'])
-            elif kind == 'spp':
-                for y in op['ys']:
-                    read(y)
-                    add(op['x'])
-            elif kind == 'from_nchw':
-                read(op['y'])
-            elif kind == 'to_nchw':
-                for off, n in op['x'].segments:
-                    mark(*span(op['x'], off, n))
-        return stores, need_zero
+        return gradient_write_modes(self.ops, [c for c, _, _ in self.pb.buffers])
 
     def _lower_backward(self):
         B, st = self.batch, self.state

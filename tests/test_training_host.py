@@ -137,3 +137,31 @@ def test_bucket_plan_waits_for_every_tensor_inside_a_bucket():
     plan.bwd = [('mark', (b,), 'mark', None), ('mark', (c,), 'mark', None), ('mark', (a,), 'mark', None)]
     got = plan._bucket_plan(red)
     assert got == {1: [1, 2], 2: [0]}
+
+
+def test_gradient_write_modes_first_writer_stores():
+    """Symbolic walk of the backward pass (train_engine.gradient_write_modes) on the op list of an elan block: the last
+    consumer in forward order of every gradient range is its first writer and stores, the other consumers add; a
+    gradient whose first writer is an adding kernel (pool / upsample backward) keeps its zero fill."""
+    from objectdetection_amd import train_engine as te
+    from objectdetection_amd.engine import PlanBuilder, BF16
+    from objectdetection_amd.model import layer
+
+    pb = PlanBuilder(2, BF16, torch.device('cpu'))
+    mod = layer.elan(in_=32, out_=64, n=2)
+    x = pb.from_nchw(32, 16, 16)
+    out = mod._emit(pb, x)
+    up = pb.upsample2(out)                      # a gradient that only an adding kernel writes
+    pb.to_nchw(up)
+    stores, need_zero = te.gradient_write_modes(pb.ops, [c for c, _, _ in pb.buffers])
+    convs = [op for op in pb.ops if op['kind'] == 'conv']
+    # the final 1x1 over the concat is the first writer of the whole concat buffer
+    assert id(convs[-1]) in stores
+    # cbs1 / cbs2 read the block input: exactly one of them stores (the later one in forward order), the other adds
+    first_two = [op for op in convs if op['x'].buf == x.buf]
+    assert len(first_two) == 2 and [id(op) in stores for op in first_two] == [False, True]
+    # chain convolutions read slices of the concat that its final 1x1 has already written: they add
+    chain = [op for op in convs[:-1] if op['x'].buf == convs[-1]['x'].buf]
+    assert chain and not any(id(op) in stores for op in chain)
+    # the upsample's input gradient is written by upsample2_bwd (adds) first: that buffer keeps its zero fill; nothing else does
+    assert need_zero == {out.buf}
