@@ -512,7 +512,7 @@ class TrainPlan:
         packed weights where one of them serves the launch (bf16; they apply scale and shift, here 1 and 0), else the
         plain [rows][row_len] order.  Returns (tensor, PackDesc fragment code)."""
         frag = 0
-        if self.PACKED_WEIGHTS and self.dtype == BF16 and not d.in_upzero2 and not d.accumulate:
+        if self.PACKED_WEIGHTS and self.dtype == BF16 and not d.in_upzero2 and not d.accumulate and d.cout <= 4096:
             if getattr(self, '_unit', None) is None:
                 self._unit = (torch.ones(4096, dtype=torch.float32, device=self.dev),
                               torch.zeros(4096, dtype=torch.float32, device=self.dev))
