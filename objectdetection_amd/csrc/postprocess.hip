@@ -965,18 +965,19 @@ iou_mask_win_kernel(const float4* __restrict__ sbox, const float4* __restrict__ 
     }
 }
 
-constexpr int SCAN_GROUP = 256;                       // threads that share a tile's update: one column word each
+constexpr int SCAN_GROUP = 256;                       // threads that share a tile's update
 constexpr int SCAN_GROUPS = 2;                        // thread groups; group g owns the tiles t with t % SCAN_GROUPS == g
 constexpr int SCAN_THREADS = SCAN_GROUP * SCAN_GROUPS;
+constexpr int SCAN_PAIRS = SCAN_GROUP / 2;            // column-word pairs one group covers from registers
 
 // One workgroup per image.  `removed` (n_pad bits) lives in LDS for the chunk and in global
 // memory between chunks.  Per 64-row tile: the first wave of the owning group resolves the tile serially
-// from its 64 diagonal words (uniform scalar work), then the group's threads OR the kept rows' words into
-// the later part of `removed`.  The greedy order makes the tiles a serial chain, and a tile's mask words
-// cannot be consumed before it is resolved, so what bounds the chain is how far ahead they were requested:
-// every group loads the rows of ITS next tile (64 words per thread) right after finishing a tile, i.e.
-// SCAN_GROUPS tiles before they are needed, and the memory latency of one group hides behind the tiles
-// of the others.
+// from its 64 diagonal words (a chain of scalar instructions), then the group's threads OR the kept rows'
+// words into the later part of `removed`: thread (pair, half) holds the two column words 2*pair, 2*pair+1 of
+// the 32 rows of its half (32 16-byte loads: a wave never has more loads in flight than its counter of
+// outstanding loads can express, so issuing them does not stall).  The greedy order makes the tiles a serial
+// chain; what bounds it is the chain itself plus the update of `removed`, so everything else sits beside it:
+// a group issues the loads of ITS next tile at the start of the iteration in which the other group resolves.
 __global__ void __launch_bounds__(SCAN_THREADS)
 nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int* __restrict__ count,
                 const int* __restrict__ srow, u64* __restrict__ removed_g, int n_pad, int row_begin, int row_end,
@@ -994,74 +995,96 @@ nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int*
     for (int w = threadIdx.x; w < nwords; w += SCAN_THREADS) removed[w] = rg[w];
     if (threadIdx.x == 0) kept_total = keep_count[b];
     __syncthreads();
-    const int group = threadIdx.x / SCAN_GROUP, w0 = threadIdx.x % SCAN_GROUP;
+    const int group = __builtin_amdgcn_readfirstlane(threadIdx.x / SCAN_GROUP);       // wave-uniform
+    const int w0 = threadIdx.x % SCAN_GROUP;
     const int lane = threadIdx.x & 63;
-    const bool resolver = w0 < 64;                    // first wave of the group
+    const bool resolver = __builtin_amdgcn_readfirstlane(w0) < 64;                    // first wave of the group
+    const int pair = w0 % SCAN_PAIRS, half = __builtin_amdgcn_readfirstlane(w0 / SCAN_PAIRS);
+    const bool pair_ok = 2 * pair + 1 < words && 2 * pair < nwords;                    // both words exist in a row
     const int t_begin = row_begin >> 6;
     const int t_end = (min(row_end, n) + 63) >> 6;
     // this group's next tile: the first one at or after t_begin with t % SCAN_GROUPS == group
     int mine = t_begin + (group - t_begin % SCAN_GROUPS + SCAN_GROUPS) % SCAN_GROUPS;
     u64 diag_next = 0;
-    u64 v[64];
-    auto fetch = [&](int t) {                          // diagonal words and row words of tile t (wave-uniform t)
+    int srow_next = 0;
+    ulonglong2 v[32];
+    auto fetch_diag = [&](int t) {                     // diagonal words and row indices of tile t (wave-uniform t)
+        if (t >= t_end || !resolver) return;
+        const int i = t * 64 + lane;
+        diag_next = (i < n) ? m[(size_t)(i - row_begin) * words + t] : 0ull;
+        srow_next = (i < n) ? srow[(size_t)b * n_pad + i] : 0;
+    };
+    auto fetch_rows = [&](int t) {                     // this thread's two column words of its 32 rows of tile t
         if (t >= t_end) return;
-        if (resolver) {
-            const int i = t * 64 + lane;
-            diag_next = (i < n) ? m[(size_t)(i - row_begin) * words + t] : 0ull;
-        }
-        if (w0 > t && w0 < nwords) {
-            const u64* m0 = m + (size_t)(t * 64 - row_begin) * words;
+        if (pair_ok && 2 * pair + 1 > t) {
+            const u64* m0 = m + (size_t)(t * 64 + half * 32 - row_begin) * words + 2 * pair;
 #pragma unroll
-            for (int u = 0; u < 64; ++u) v[u] = m0[(size_t)u * words + w0];
+            for (int u = 0; u < 32; ++u) v[u] = *(const ulonglong2*)(m0 + (size_t)u * words);
         }
     };
-    fetch(mine);
+    fetch_diag(mine);
+    fetch_rows(mine);
+    bool rows_pending = false;
     for (int t = t_begin; t < t_end; ++t) {
         const bool owner = t == mine;                  // uniform within a group
+        if (rows_pending) {                            // never the owner: it fetched SCAN_GROUPS - 1 tiles ago
+            fetch_rows(mine);
+            rows_pending = false;
+        }
         if (owner && resolver) {
-            const int i = t * 64 + lane;
-            const u64 diag = diag_next;
+            const u64 diag = ~diag_next;              // complemented once, in all lanes: a step then only ANDs
             const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
-            const u64 rem = removed[t];
-            // wave-uniform state in scalar registers: the 64-step chain below is scalar work
+            u64 rem = removed[t];
+            if (n - t * 64 < 64) rem |= ~((1ull << (n - t * 64)) - 1ull);
+            // wave-uniform state in scalar registers: the 64-step chain below is scalar work.  A row's word
+            // only has bits of strictly later rows, so bit q is final once step q has looked at it: what is
+            // left of `alive` after the last step is the set of kept rows.
             u64 alive = ~(((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rem >> 32)) << 32) |
                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rem));
-            if (n - t * 64 < 64) alive &= (1ull << (n - t * 64)) - 1ull;
-            u64 kept = 0;
 #pragma unroll
             for (int q = 0; q < 64; ++q) {
                 const u64 dq = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)dhi, q) << 32) |
                                (uint32_t)__builtin_amdgcn_readlane((int)dlo, q);
-                if ((alive >> q) & 1ull) {
-                    kept |= 1ull << q;
-                    alive &= ~dq;
-                }
+                // alive &= alive[q] ? dq : ~0, as the three scalar instructions it is (the compiler's own
+                // sequence shifts and tests 32-bit halves: five dependent instructions a step)
+                u64 pick;
+                asm volatile("s_bitcmp1_b64 %0, %3\n\ts_cselect_b64 %1, %2, -1\n\ts_and_b64 %0, %0, %1"
+                             : "+s"(alive), "=&s"(pick) : "s"(dq), "i"(q) : "scc");
             }
+            const u64 kept = alive;
             const int base = kept_total;
-            if ((kept >> lane) & 1ull) {
-                const int pos = base + __popcll(kept & ((1ull << lane) - 1ull));
-                if (pos < max_keep) keep_idx[(size_t)b * max_keep + pos] = srow[(size_t)b * n_pad + i];
-            }
             if (lane == 0) {
                 kept_bits = kept;
                 kept_total = base + __popcll(kept);
                 removed[t] |= ~kept;  // every row of a finished tile is decided
             }
+            if ((kept >> lane) & 1ull) {
+                const int pos = base + __popcll(kept & ((1ull << lane) - 1ull));
+                if (pos < max_keep) keep_idx[(size_t)b * max_keep + pos] = srow_next;
+            }
         }
         __syncthreads();
         if (owner) {
-            const u64 kept = kept_bits;
+            const u64 kept_all = kept_bits;
+            const u64 kept = ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(kept_all >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)kept_all);
             const u64* mt = m + (size_t)(t * 64 - row_begin) * words;
-            // column word w0: its 64 row words of this tile were loaded SCAN_GROUPS tiles ago (the loads do not
-            // depend on the outcome: rows that were not kept are masked out)
-            if (w0 > t && w0 < nwords) {
-                u64 acc = 0;
+            // the rows' words were loaded SCAN_GROUPS tiles ago (the loads do not depend on the outcome: rows
+            // that were not kept are masked out)
+            if (pair_ok && 2 * pair + 1 > t) {
+                const uint32_t kh = half ? (uint32_t)(kept >> 32) : (uint32_t)kept;    // this half's 32 rows
+                u64 acc0 = 0, acc1 = 0;
 #pragma unroll
-                for (int u = 0; u < 64; ++u) acc |= ((kept >> u) & 1ull) ? v[u] : 0ull;
-                removed[w0] |= acc;
+                for (int u = 0; u < 32; ++u) {
+                    const u64 on = 0ull - (u64)((kh >> u) & 1u);                        // uniform: all ones for a kept row
+                    acc0 |= v[u].x & on;
+                    acc1 |= v[u].y & on;
+                }
+                if (2 * pair > t && acc0) atomicOr((unsigned long long*)&removed[2 * pair], (unsigned long long)acc0);
+                if (2 * pair + 1 < nwords && acc1) atomicOr((unsigned long long*)&removed[2 * pair + 1], (unsigned long long)acc1);
             }
             // further column words (more than 16384 candidates): loaded here, four batches of 16
-            for (int w = w0 + SCAN_GROUP; w < nwords; w += SCAN_GROUP) {
+            for (int w = w0 + 2 * SCAN_PAIRS; w < nwords; w += SCAN_GROUP) {
                 if (w <= t) continue;
                 u64 acc = 0;
 #pragma unroll 1
@@ -1075,7 +1098,8 @@ nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int*
                 removed[w] |= acc;
             }
             mine += SCAN_GROUPS;
-            fetch(mine);                               // in flight while the other groups' tiles are processed
+            fetch_diag(mine);                          // two loads; the rows follow at the top of the next iteration
+            rows_pending = true;
         }
         __syncthreads();
     }
