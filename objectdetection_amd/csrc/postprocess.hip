@@ -969,6 +969,7 @@ constexpr int SCAN_GROUP = 256;                       // threads that share a ti
 constexpr int SCAN_GROUPS = 2;                        // thread groups; group g owns the tiles t with t % SCAN_GROUPS == g
 constexpr int SCAN_THREADS = SCAN_GROUP * SCAN_GROUPS;
 constexpr int SCAN_PAIRS = SCAN_GROUP / 2;            // column-word pairs one group covers from registers
+constexpr int SCAN_SPARSE_ROWS = 20;                  // up to this many rows with in-tile bits: loop over them alone
 
 // One workgroup per image.  `removed` (n_pad bits) lives in LDS for the chunk and in global
 // memory between chunks.  Per 64-row tile: the first wave of the owning group resolves the tile serially
@@ -1041,6 +1042,17 @@ nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int*
             // left of `alive` after the last step is the set of kept rows.
             u64 alive = ~(((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rem >> 32)) << 32) |
                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rem));
+            // rows whose word is empty inside the tile cannot change `alive`: with few others, visit only those
+            u64 todo = __ballot(diag != ~0ull) & alive;
+            if (__popcll(todo) <= SCAN_SPARSE_ROWS) {
+                while (todo) {
+                    const int q = __builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    const u64 dq = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)dhi, q) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readlane((int)dlo, q);
+                    if ((alive >> q) & 1ull) alive &= dq;
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < 64; ++q) {
                 const u64 dq = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)dhi, q) << 32) |
