@@ -1493,7 +1493,8 @@ int odamd_maxpool2_backward(const void* x, int x_ld, const void* dy, int dy_ld, 
     if (!x || !dy || !dx || batch < 1 || h < 2 || w < 2 || c < 1) return ODAMD_E_ARG;
     const int per = dtype == ODAMD_DTYPE_F32 ? 4 : 8;
     if (dtype != ODAMD_DTYPE_F32 && dtype != ODAMD_DTYPE_BF16) return ODAMD_E_ARG;
-    if (c % per) return ODAMD_E_ALIGN;
+    if ((c % per) || (x_ld % per) || (dy_ld % per) || (dx_ld % per) || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15))
+        return ODAMD_E_ALIGN;             // the kernel moves whole 16-byte channel vectors
     const int vecs = c / per;
     const size_t n = (size_t)batch * (h / 2) * (w / 2) * vecs;
     if (dtype == ODAMD_DTYPE_F32)
@@ -1551,7 +1552,7 @@ int odamd_upsample2_backward(const void* dy, int dy_ld, void* dx, int dx_ld, int
     if (!dy || !dx || batch < 1 || h < 1 || w < 1 || c < 1) return ODAMD_E_ARG;
     if (dtype != ODAMD_DTYPE_F32 && dtype != ODAMD_DTYPE_BF16) return ODAMD_E_ARG;
     const int per = dtype == ODAMD_DTYPE_F32 ? 4 : 8;
-    if (c % per) return ODAMD_E_ALIGN;
+    if ((c % per) || (dy_ld % per) || (dx_ld % per) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15)) return ODAMD_E_ALIGN;
     const int vecs = c / per;
     const size_t n = (size_t)batch * h * w * vecs;
     if (dtype == ODAMD_DTYPE_F32)
