@@ -441,12 +441,25 @@ __device__ __forceinline__ void cmpex(u64& lo, u64& hi, bool desc) {
     if (sw) { const u64 t = lo; lo = hi; hi = t; }
 }
 
+// The keys of an image sit compacted at the front and every real key is above the padding, so sorting the
+// first P keys, P = the power of two that holds them (at least one chunk), sorts the whole array: the network
+// on that prefix is the network of the whole array cut off after stage k = P, and (i & P) == 0 makes its last
+// stage descending.  Workgroups beyond P and stages beyond k = P return at once.
+__device__ __forceinline__ int sort_extent(const int* __restrict__ count, int b, int n_pad, int chunk) {
+    if (!count) return n_pad;
+    const int n = min(count[b], n_pad);
+    if (n <= chunk) return chunk;
+    return min(n_pad, 1 << (32 - __clz(n - 1)));
+}
+
 // All stages with k <= chunk (FULL) or the j < chunk tail of stage k_outer (!FULL), in LDS.
 template <bool FULL>
-__global__ void __launch_bounds__(SORT_THREADS) bitonic_lds_kernel(u64* __restrict__ keys, int n_pad, int chunk, int k_outer) {
+__global__ void __launch_bounds__(SORT_THREADS) bitonic_lds_kernel(u64* __restrict__ keys, const int* __restrict__ count, int n_pad, int chunk, int k_outer) {
     __shared__ u64 s[SORT_CHUNK];
     u64* base = keys + (size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * chunk;
     const int g0 = blockIdx.x * chunk;
+    const int extent = sort_extent(count, blockIdx.y, n_pad, chunk);
+    if (g0 >= extent || (!FULL && k_outer > extent)) return;
     for (int i = threadIdx.x; i < chunk; i += SORT_THREADS) s[i] = base[i];
     __syncthreads();
     for (int k = FULL ? 2 : k_outer; k <= (FULL ? chunk : k_outer); k <<= 1) {
@@ -466,11 +479,13 @@ __global__ void __launch_bounds__(SORT_THREADS) bitonic_lds_kernel(u64* __restri
 }
 
 // One compare-exchange stage (k, j) with j >= chunk, straight in global memory.
-__global__ void __launch_bounds__(256) bitonic_global_kernel(u64* __restrict__ keys, int n_pad, int k, int j) {
+__global__ void __launch_bounds__(256) bitonic_global_kernel(u64* __restrict__ keys, const int* __restrict__ count, int n_pad, int chunk, int k, int j) {
     u64* base = keys + (size_t)blockIdx.y * n_pad;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_pad / 2) return;
+    const int extent = sort_extent(count, blockIdx.y, n_pad, chunk);
     const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+    if (k > extent || i >= extent) return;
     const bool desc = ((i & k) == 0);
     u64 a = base[i], c = base[i + j];
     const bool sw = desc ? (a < c) : (a > c);
@@ -1416,14 +1431,14 @@ Workspace carve(char* base, int batch, int rows, int n_pad) {
     return w;
 }
 
-int sort_keys(u64* keys, int batch, int n_pad, hipStream_t st) {
+int sort_keys(u64* keys, const int* count, int batch, int n_pad, hipStream_t st) {
     const int chunk = n_pad < SORT_CHUNK ? n_pad : SORT_CHUNK;
     dim3 grid_l(n_pad / chunk, batch);
-    bitonic_lds_kernel<true><<<grid_l, SORT_THREADS, 0, st>>>(keys, n_pad, chunk, 0);
+    bitonic_lds_kernel<true><<<grid_l, SORT_THREADS, 0, st>>>(keys, count, n_pad, chunk, 0);
     for (int k = chunk * 2; k <= n_pad; k <<= 1) {
         for (int j = k >> 1; j >= chunk; j >>= 1)
-            bitonic_global_kernel<<<dim3((n_pad / 2 + 255) / 256, batch), 256, 0, st>>>(keys, n_pad, k, j);
-        bitonic_lds_kernel<false><<<grid_l, SORT_THREADS, 0, st>>>(keys, n_pad, chunk, k);
+            bitonic_global_kernel<<<dim3((n_pad / 2 + 255) / 256, batch), 256, 0, st>>>(keys, count, n_pad, chunk, k, j);
+        bitonic_lds_kernel<false><<<grid_l, SORT_THREADS, 0, st>>>(keys, count, n_pad, chunk, k);
     }
     return (int)hipGetLastError();
 }
@@ -1500,7 +1515,7 @@ int postprocess_impl(const float* pred, const DecodeGeom& g, int batch, int rows
     filter_kernel<SRC><<<fgrid, FILTER_THREADS, (size_t)rows_stage * ldk * 4, st>>>(
         fs, g, rows, kdim, rows_stage, conf_thr, w.rowbox, w.keys, n_pad, w.count_pad);
     compact_counts_kernel<<<(batch + 255) / 256, 256, 0, st>>>(w.count_pad, batch, n_pad, w.count);
-    if ((rc = sort_keys(w.keys, batch, n_pad, st))) return rc;
+    if ((rc = sort_keys(w.keys, w.count, batch, n_pad, st))) return rc;
     gather_sorted_kernel<<<dim3((n_pad + 255) / 256, batch), 256, 0, st>>>(w.keys, w.rowbox, w.count, rows, n_pad,
                                                                            SRC >= 3, w.sbox, w.srow);
     if ((rc = run_nms(w, w.count, batch, rows, n_pad, iou_thr, SRC >= 3, out_idx, out_count, max_keep, st))) return rc;
