@@ -1388,6 +1388,32 @@ layout_kernel(const char* __restrict__ x, char* __restrict__ y, int C, int HW, i
     }
 }
 
+// NCHW float32 planes -> NHWC pixels of eight channels, for tensors of at most eight channels (the image): one
+// thread per pixel reads its value from every plane (coalesced along the plane) and writes the pixel's whole
+// vector, channels beyond C as zeros.  The tile kernel above would use 3 of its 32 channel lanes here.
+template <int DT>
+__global__ void __launch_bounds__(256)
+few_planes_to_nhwc8_kernel(const float* __restrict__ x, char* __restrict__ y, int C, size_t HW, int Ct, size_t npix) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / HW, pp = i % HW;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = c < C ? x[(b * Ct + c) * HW + pp] : 0.0f;
+        if (DT == ODAMD_DTYPE_F32) {
+            float4* o = (float4*)(y + i * 32);
+            o[0] = make_float4(v[0], v[1], v[2], v[3]);
+            o[1] = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            uint4 o;
+            o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+            o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+            *(uint4*)(y + i * 16) = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -2145,6 +2171,18 @@ int odamd_upsample2_forward(const void* x, void* y, int batch, int h, int w, int
 int odamd_nchw_to_nhwc(const float* x, void* y, int batch, int c, int h, int w, int x_c, int y_ld, int dtype,
                        void* stream) {
     if (!x || !y || batch < 1 || c < 1 || h < 1 || w < 1 || y_ld < c || x_c < c) return ODAMD_E_ARG;
+    if (dtype != ODAMD_DTYPE_F32 && dtype != ODAMD_DTYPE_BF16) return ODAMD_E_ARG;
+    // few planes into whole eight-channel pixels (the image): y has to start at a pixel, which a channel offset inside
+    // an eight-channel row never does at this alignment
+    if (c <= 8 && y_ld == 8 && ((uintptr_t)y & (dtype == ODAMD_DTYPE_F32 ? 31 : 15)) == 0) {
+        const size_t npix = (size_t)batch * h * w;
+        const unsigned blocks = (unsigned)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
+        if (dtype == ODAMD_DTYPE_F32)
+            few_planes_to_nhwc8_kernel<ODAMD_DTYPE_F32><<<blocks, 256, 0, (hipStream_t)stream>>>(x, (char*)y, c, (size_t)h * w, x_c, npix);
+        else
+            few_planes_to_nhwc8_kernel<ODAMD_DTYPE_BF16><<<blocks, 256, 0, (hipStream_t)stream>>>(x, (char*)y, c, (size_t)h * w, x_c, npix);
+        return (int)hipGetLastError();
+    }
     dim3 grid((h * w + 31) / 32, (c + 31) / 32, batch);
     if (dtype == ODAMD_DTYPE_F32)
         layout_kernel<ODAMD_DTYPE_F32, true><<<grid, 256, 0, (hipStream_t)stream>>>((const char*)x, (char*)y, c, h * w, y_ld, x_c);
