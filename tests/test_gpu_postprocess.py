@@ -83,6 +83,26 @@ def test_postprocess_matches_oracle_bit_exact(pp, n, ncls, dense, cthr, ithr):
         assert np.array_equal(res[b][0], rows)
 
 
+def test_candidate_counts_far_below_the_padded_row_count(pp):
+    """Images of one batch whose candidates fill 1 %, 25 %, 50 % and nearly all of the 20 000 rows (padded to
+    32 768 sort keys): the sort works on the power-of-two prefix that holds an image's candidates (one 4 096-key
+    chunk, 8 192, 16 384 and all 32 768 keys here), and the order has to be the full sort's."""
+    n, ncls = 20000, 3
+    preds = np.stack([_synthetic_pred(300 + b, n, ncls, 640) for b in range(4)])
+    for b, keep_frac in enumerate((0.012, 0.25, 0.5, 0.97)):
+        # confidence * best class score >= 0.25 for about keep_frac of the rows
+        preds[b, :, 5:] = 1.0
+        preds[b, :, 4] = np.where(np.random.default_rng(b).uniform(0, 1, n) < keep_frac, 0.3 + 0.7 * preds[b, :, 4], 0.2 * preds[b, :, 4])
+    res = pp.postprocess(torch.from_numpy(preds).cuda(), 0.25, 0.5)
+    cand = res.cand.cpu().numpy()
+    assert cand[0] <= 4096 < cand[1] <= 8192 < cand[2] <= 16384 < cand[3], cand
+    out = res.per_image()
+    for b in range(4):
+        rows, kept = opost.predict_decode(preds[b], (640, 640, 3), 640, 0.25, 0.5)
+        assert np.array_equal(out[b][1], kept), f'image {b}'
+        assert np.array_equal(out[b][0], rows)
+
+
 @pytest.mark.parametrize('ithr', [0.3, 0.5, 0.7, 0.02, 0.98, 0.0, 1.0, 1.5])
 def test_nms_mixed_scales_and_irregular_boxes(pp, ithr):
     """Boxes from 2 to 400 pixels (log-uniform, all shapes) in overlapping clusters, with zero, negative,
