@@ -397,3 +397,21 @@ def test_pruned_network_vs_reference_fixture(od, golden):
     got = net.cuda().eval()(patterns.image_batch(2, 64).cuda()).cpu().numpy()
     assert rel_err(got[..., :4], g['eval'][..., :4]) < TOL['f32']
     assert rel_err(got[..., 4:], g['eval'][..., 4:]) < TOL['f32']
+
+
+@pytest.mark.parametrize('c,ld,dt', [(3, 8, 'f32'), (3, 8, 'bf16'), (8, 8, 'bf16'), (1, 8, 'f32'), (5, 16, 'bf16'), (3, 4, 'f32')])
+def test_nchw_to_nhwc_layouts(c, ld, dt):
+    """NCHW float32 planes -> NHWC rows of `ld` channels: the per-pixel kernel for at most eight planes into
+    eight-channel pixels (padding channels written as zeros) and the tiled kernel for everything else."""
+    from objectdetection_amd._lib import lib, check
+    from objectdetection_amd.engine import F32, BF16
+    b, h, w = 2, 37, 41
+    x = torch.randn(b, c, h, w, generator=torch.Generator().manual_seed(c * 10 + ld)).cuda()
+    tdt = torch.float32 if dt == 'f32' else torch.bfloat16
+    y = torch.zeros(b, h, w, ld, dtype=tdt, device='cuda')
+    check(lib.odamd_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), b, c, h, w, c, ld, F32 if dt == 'f32' else BF16,
+                                 torch.cuda.current_stream().cuda_stream), 'nchw_to_nhwc')
+    torch.cuda.synchronize()
+    ref = torch.zeros(b, h, w, ld, dtype=tdt, device='cuda')
+    ref[..., :c] = x.permute(0, 2, 3, 1).to(tdt)
+    assert torch.equal(y, ref)
