@@ -1224,30 +1224,64 @@ __device__ __forceinline__ size_t frag_index(int frag, int row, int tap, int col
     return ((((((size_t)cb * nch + ch) * groups + g) * taps + tap) * ksn + s) * 2 + half) * 256 + r * 8 + e;
 }
 
-__global__ void __launch_bounds__(256) pack_weights_kernel(const PackDesc* __restrict__ table, int dtype) {
-    const PackDesc d = table[blockIdx.y];
+// One destination of one layer.  A workgroup takes whole destination rows, a thread a column of the row, and walks
+// the taps innermost: the index arithmetic (divisions by the layer's channel and chunk counts, the segment search)
+// happens once per (row, column) instead of once per element, a thread reads the k*k contiguous source weights of its
+// (output, input) channel pair, and the lanes of a wave write neighbouring columns.
+// BWD: rows are physical input channels, columns output channels, taps flipped.
+template <bool BWD>
+__device__ __forceinline__ void pack_weights_pass(const PackDesc& d, int dtype) {
     const int kk = d.k * d.k;
-    const size_t n = (size_t)d.cout * d.cin * kk;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int t = i % kk;
-        const int ci = (i / kk) % d.cin;
-        const int co = i / ((size_t)kk * d.cin);
-        const float v = d.w[i];
-        int phys = ci, rem = ci;                     // logical -> physical input channel
-        for (int s = 0; s < d.n_seg; ++s) {
-            if (rem < d.seg_len[s]) { phys = d.seg_off[s] + rem; break; }
-            rem -= d.seg_len[s];
+    const int frag = BWD ? d.bwd_frag : d.fwd_frag;
+    const int rows = BWD ? d.cin_phys : d.cout;
+    const int cols = BWD ? d.cout_phys : d.cin_phys;
+    char* dst = (char*)(BWD ? d.bwd : d.fwd);
+    const bool f32 = dtype == ODAMD_DTYPE_F32 || (!BWD && d.fwd_f32);
+    const int groups = frag & 255, chunk = frag >> 8;
+    const int ksn = frag ? chunk / 32 : 1, nch = frag ? cols * 2 / chunk : 1, cpc = frag ? chunk / 2 : 1;
+    // physical -> logical input channel, -1 for padding.  All eight slots with constant indices: a loop to n_seg
+    // indexes the descriptor dynamically, which puts every thread's copy of it into private memory.
+    auto logical = [&](int phys) {
+        int first = 0, ci = -1;
+#pragma unroll
+        for (int sgm = 0; sgm < 8; ++sgm) {
+            const int off = d.seg_off[sgm], len = sgm < d.n_seg ? d.seg_len[sgm] : 0;
+            if (ci < 0 && phys >= off && phys < off + len) ci = first + phys - off;
+            first += len;
         }
-        if (d.fwd) {
-            const size_t o = d.fwd_frag ? frag_index(d.fwd_frag, co, t, phys, kk, d.cin_phys) : ((size_t)co * kk + t) * d.cin_phys + phys;
-            if (dtype == ODAMD_DTYPE_F32 || d.fwd_f32) ((float*)d.fwd)[o] = v; else ((uint16_t*)d.fwd)[o] = f32_to_bf16(v);
-        }
-        if (d.bwd) {
-            const size_t o = d.bwd_frag ? frag_index(d.bwd_frag, phys, kk - 1 - t, co, kk, d.cout_phys)
-                                        : ((size_t)phys * kk + (kk - 1 - t)) * d.cout_phys + co;
-            if (dtype == ODAMD_DTYPE_F32) ((float*)d.bwd)[o] = v; else ((uint16_t*)d.bwd)[o] = f32_to_bf16(v);
+        return ci;
+    };
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int row_ci = BWD ? logical(row) : 0;
+        if (BWD && row_ci < 0) continue;             // padding stays zero
+        for (int col = threadIdx.x; col < cols; col += 256) {
+            const int co = BWD ? col : row;
+            const int ci = BWD ? row_ci : logical(col);
+            if (co >= d.cout || ci < 0) continue;
+            size_t base, tap_stride;
+            if (frag) {                              // [rows / 32G][chunk][G][tap][k-step][2][32][8], see frag_index
+                const int cb = row / (32 * groups), g = (row >> 5) % groups, r = row & 31;
+                const int ch = col / cpc, ks = (col - ch * cpc) >> 4, half = (col >> 3) & 1, e = col & 7;
+                tap_stride = (size_t)ksn * 512;
+                base = (((size_t)cb * nch + ch) * groups + g) * kk * tap_stride + (size_t)(ks * 2 + half) * 256 + r * 8 + e;
+            } else {                                 // [row][tap][col]
+                tap_stride = (size_t)cols;
+                base = (size_t)row * kk * cols + col;
+            }
+            const float* src = d.w + ((size_t)co * d.cin + ci) * kk;
+            for (int tap = 0; tap < kk; ++tap) {
+                const float v = src[BWD ? kk - 1 - tap : tap];
+                const size_t o = base + (size_t)tap * tap_stride;
+                if (f32) ((float*)dst)[o] = v; else ((uint16_t*)dst)[o] = f32_to_bf16(v);
+            }
         }
     }
+}
+
+__global__ void __launch_bounds__(256) pack_weights_kernel(const PackDesc* __restrict__ table, int dtype) {
+    const PackDesc& d = table[blockIdx.y];           // uniform: scalar loads, no per-thread copy
+    if (d.fwd) pack_weights_pass<false>(d, dtype);
+    if (d.bwd) pack_weights_pass<true>(d, dtype);
 }
 
 int red_geometry(int C, int dtype, int* vecs, int* rows) {
@@ -1668,7 +1702,8 @@ int odamd_ema_update(float* ema, const float* src, size_t n, double decay, void*
 int odamd_pack_weights(const void* table_dev, int n_entries, int dtype, void* stream) {
     if (!table_dev || n_entries < 1) return ODAMD_E_ARG;
     if (dtype != ODAMD_DTYPE_F32 && dtype != ODAMD_DTYPE_BF16) return ODAMD_E_ARG;
-    pack_weights_kernel<<<dim3(64, n_entries), 256, 0, (hipStream_t)stream>>>((const PackDesc*)table_dev, dtype);
+    // 256 workgroups per layer: the largest layers (2.4 M weights) bound the launch, 36 elements per thread then
+    pack_weights_kernel<<<dim3(256, n_entries), 256, 0, (hipStream_t)stream>>>((const PackDesc*)table_dev, dtype);
     return (int)hipGetLastError();
 }
 
