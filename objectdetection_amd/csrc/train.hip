@@ -1154,11 +1154,17 @@ __global__ void __launch_bounds__(256) loss_pos_kernel(LossP p) {
     if (threadIdx.x == 0) { p.part[p.nblk + blockIdx.x] = f; p.part[2 * p.nblk + blockIdx.x] = c; }
 }
 
-__global__ void loss_finalize_kernel(LossP p, int nconf, int npos) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One workgroup: thread t adds the partials t, t + 256, ... and a tree adds the threads (a fixed order; one thread
+// walking a thousand partials alone took 50 us on the path between the forward and the backward pass).
+__global__ void __launch_bounds__(256) loss_finalize_kernel(LossP p, int nconf, int npos) {
+    __shared__ double sm[256];
     double c = 0.0, f = 0.0, k = 0.0;
-    for (int i = 0; i < nconf; ++i) c += p.part[i];
-    for (int i = 0; i < npos; ++i) { f += p.part[p.nblk + i]; k += p.part[2 * p.nblk + i]; }
+    for (int i = threadIdx.x; i < nconf; i += 256) c += p.part[i];
+    for (int i = threadIdx.x; i < npos; i += 256) { f += p.part[p.nblk + i]; k += p.part[2 * p.nblk + i]; }
+    c = block_sum(c, sm);
+    f = block_sum(f, sm);
+    k = block_sum(k, sm);
+    if (threadIdx.x != 0) return;
     const float conf = (float)(100.0 * c / ((double)p.B * p.R));
     float frame = 1.0f, cls = 1.0f;                                     // no positives: constants
     const int P = loss_npos(p);
@@ -1664,7 +1670,7 @@ static int loss_launch(const float* pred, float* dpred, const int* screen, const
         if (npos > 1024) npos = 1024;
         loss_pos_kernel<<<npos, 256, 0, st>>>(p);
     }
-    loss_finalize_kernel<<<1, 64, 0, st>>>(p, nconf, npos);
+    loss_finalize_kernel<<<1, 256, 0, st>>>(p, nconf, npos);
     return (int)hipGetLastError();
 }
 
