@@ -1588,7 +1588,9 @@ int odamd_decode_backward(const odamd_decode_desc* d, const float* grad_out, flo
     if (!grad_out || !grad_head || !grad_head[0] || !grad_head[1] || !grad_head[2] || d->deploy) return ODAMD_E_ARG;
     int maxn = 0;
     for (int s = 0; s < 3; ++s) maxn = max(maxn, d->n_anchor * d->h[s] * d->w[s] * d->kdim);
-    int gx = (maxn + 255) / 256;
+    // four elements per thread of the largest map: the grid is the same for all three maps, and most workgroups of a
+    // one-element-per-thread grid belonged to the two small ones and had nothing to do
+    int gx = (maxn + 1023) / 1024;
     if (gx > 2048) gx = 2048;
     decode_bwd_kernel<<<dim3(gx, 3, d->batch), 256, 0, (hipStream_t)stream>>>(g, grad_out, grad_head[0], grad_head[1],
                                                                               grad_head[2]);
