@@ -27,8 +27,8 @@ MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}   # dense peaks
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=20)
-    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--steps', type=int, default=100)
+    p.add_argument('--warmup', type=int, default=10)
     p.add_argument('--batch', type=int, default=64, help='images per GPU per step')
     p.add_argument('--size', type=int, default=640)
     p.add_argument('--classes', type=int, default=80)
@@ -40,7 +40,7 @@ def parse():
                    help="which leg `value` reports; the other one is reported in a sub-object")
     p.add_argument('--train-batch', type=int, default=32, help='training images per GPU per step')
     p.add_argument('--train-classes', type=int, default=5)
-    p.add_argument('--train-steps', type=int, default=None, help='default: --steps')
+    p.add_argument('--train-steps', type=int, default=None, help='default: --steps, at most 40')
     p.add_argument('--no-train', action='store_true', help='skip the training leg')
     p.add_argument('--no-extra', action='store_true', help='skip the end-to-end and dense-candidate legs')
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -399,7 +399,7 @@ def main():
         guard.daemon = True
         guard.start()
         del model, x
-        tsteps = a.train_steps if a.train_steps is not None else a.steps
+        tsteps = a.train_steps if a.train_steps is not None else min(a.steps, 40)
         note('training leg f32')
         train, tc_ = train_leg(a, dev, rank, world, dist, tsteps, max(a.warmup, 2))
         note('training leg bf16')
