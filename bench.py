@@ -245,11 +245,32 @@ def note(msg):
         print(f"[bench rank {os.environ.get('RANK', 0)} +{time.perf_counter():.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` run plainly: this process becomes a launcher that never touches the GPU.  It starts
+    `python -m torch.distributed.run --nproc-per-node N` on this same script (one rank per GPU, the launch line of
+    run.py:15 of the reference), lets rank 0's JSON line pass through and returns the launcher's exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if have < n and '--share-gpu' not in sys.argv:
+        print(f'bench.py: --gpus {n} asked for, {have} GPU(s) visible', file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
     if os.environ.get('BENCH_DEBUG'):
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ.get('BENCH_DEBUG_DUMP_S', '90')), exit=False)
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))

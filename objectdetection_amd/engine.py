@@ -573,10 +573,11 @@ def _run_module_train(module, x, emit=None):
         raise RuntimeError('train mode is not available for this module')
     state = None
     for p in module.parameters():
-        state = getattr(p, '_odamd_flat', None)
+        state = train_engine.flat_state_of(p)
         break
     if state is None:
-        state = train_engine.FlatState(module)
+        # a block that trains on its own owns its flat storage (kept out of pickles by _Block.__getstate__)
+        state = module.__dict__['_odamd_state'] = train_engine.FlatState(module)
     dtype = BF16 if getattr(module, 'train_dtype', 'f32') == 'bf16' else F32
     plans = module.__dict__.setdefault('_odamd_train_plans', {})
     key = (tuple(x.shape), dtype, x.device.index)

@@ -37,7 +37,7 @@ class _Block(torch.nn.Module):
     def __getstate__(self):
         """Pickling (checkpoints pickle whole modules): execution plans and their buffers stay behind."""
         state = self.__dict__.copy()
-        for k in ('_odamd_plans', '_odamd_train_plans', '_odamd_hook'):
+        for k in ('_odamd_plans', '_odamd_train_plans', '_odamd_hook', '_odamd_state'):
             state.pop(k, None)
         return state
 

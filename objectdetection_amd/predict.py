@@ -26,32 +26,52 @@ parser.add_argument('--iou_threshold', default=0.5, type=float)
 args, _ = parser.parse_known_args()
 
 
-def load_model(model_path):
-    """Checkpoint -> yolov7 module of this build.  Two forms are accepted:
-      * {'state_dict': ..., 'meta': ...} (what train_class writes next to every checkpoint as *.weights.pt):
+def load_checkpoint(model_path, allow_pickle=True):
+    """Checkpoint file -> its dict with the yolov7 module of this build under 'model'.  The file is read once.
+    Two forms are accepted:
+      * {'state_dict': ..., 'meta': ..., ...} (what train_class writes next to every checkpoint as *.weights.pt):
         tensors and plain Python data only, read with weights_only=True, nothing in the file is executed;
       * the reference's own format (train_class.py:262-276, read like predict.py:29): a pickled dict whose
         'model' entry is the module object.  Its class paths model.yolov7.yolov7 / model.layer.* resolve to
         this build's classes through the top-level `model` package; unpickling runs code from the file, so
-        only load checkpoints you trust.
+        only load checkpoints you trust.  This form is only tried when the safe loader refused the file
+        BECAUSE it holds pickled classes (an unreadable or truncated file is an error, not a reason to unpickle),
+        a warning says so, and `allow_pickle=False` (or ODAMD_NO_PICKLE=1) turns it off.
     Anything that does not come out as this build's yolov7 is refused: nothing here runs a network through
     torch's own operators."""
+    import os
+    import pickle
+    import warnings
     from .model.yolov7 import yolov7
-    ckpt = None
     try:
         ckpt = torch.load(model_path, map_location='cpu', weights_only=True)
-    except Exception:                                    # a pickled module: not loadable without running code
-        ckpt = None
+    except pickle.UnpicklingError as e:
+        text = str(e)
+        if not ('Unsupported global' in text or 'weights_only' in text or 'GLOBAL' in text):
+            raise
+        if not allow_pickle or os.environ.get('ODAMD_NO_PICKLE'):
+            raise RuntimeError(f'{model_path}: holds pickled objects and loading them is disabled; use the '
+                               '*.weights.pt file written next to it') from e
+        warnings.warn(f'{model_path}: reference-format checkpoint (a pickled module): unpickling executes code '
+                      'from the file', stacklevel=2)
+        ckpt = torch.load(model_path, map_location='cpu', weights_only=False)
     if isinstance(ckpt, dict) and 'state_dict' in ckpt and 'meta' in ckpt:
-        return yolov7.from_checkpoint(ckpt)
-    ckpt = torch.load(model_path, map_location='cpu', weights_only=False)
-    model = ckpt['model'] if isinstance(ckpt, dict) else ckpt
-    model = getattr(model, 'module', model)
+        out = {k: v for k, v in ckpt.items() if k not in ('state_dict', 'meta')}
+        out['model'] = yolov7.from_checkpoint(ckpt)
+        return out
+    out = dict(ckpt) if isinstance(ckpt, dict) else {'model': ckpt}
+    model = getattr(out.get('model'), 'module', out.get('model'))
     if not isinstance(model, yolov7):
         raise TypeError(f'{model_path}: holds a {type(model).__module__}.{type(model).__name__}, not the yolov7 of '
                         'objectdetection_amd (put this repository ahead of the reference tree on sys.path so that '
                         'model.yolov7 resolves to it); there is no fallback through torch operators')
-    return model
+    out['model'] = model
+    return out
+
+
+def load_model(model_path, allow_pickle=True):
+    """The yolov7 module of a checkpoint (see load_checkpoint)."""
+    return load_checkpoint(model_path, allow_pickle)['model']
 
 
 class predict_class:

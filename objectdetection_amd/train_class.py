@@ -89,6 +89,7 @@ class FusedAdam:
 
     def __init__(self, model, lr, betas=(0.937, 0.999), weight_decay=0.0, eps=1e-8):
         self.state = model.train_state()
+        self.params = list(model.parameters())
         self.param_groups = [{'lr': lr, 'betas': betas, 'weight_decay': weight_decay, 'eps': eps}]
         self.grad_scale = 1.0
         self.ema = False
@@ -106,7 +107,21 @@ class FusedAdam:
                 'param_groups': [dict(g) for g in self.param_groups]}
 
     def load_state_dict(self, d):
+        """Takes this class's own state_dict, or torch.optim.Adam's (what a reference checkpoint holds,
+        train_class.py:166-167: per-parameter entries in model.parameters() order)."""
         s = self.state
+        if 'state' in d:
+            step = 0
+            for i, p in enumerate(self.params):
+                e = d['state'].get(i)
+                if e is None:
+                    continue
+                o = s.offsets[id(p)]
+                s.exp_avg[o:o + p.numel()].copy_(e['exp_avg'].reshape(-1))
+                s.exp_avg_sq[o:o + p.numel()].copy_(e['exp_avg_sq'].reshape(-1))
+                step = max(step, int(e['step']))
+            s.step = step
+            return
         s.step = d['step']
         s.exp_avg.copy_(d['exp_avg'])
         s.exp_avg_sq.copy_(d['exp_avg_sq'])
@@ -315,27 +330,19 @@ class train_class:
             self.ema = model_ema(self.model)
             self.ema.update_total = self.model_dict['ema_update']
             self.optimizer.ema = True
-        self.reducer = None
+        self.reducer = self.parallel = None
         if args.distributed:
-            import torch.distributed as dist
-            st = self.model.train_state()
             # every rank starts from rank 0's parameters and buffers (DDP constructor broadcast)
-            te.broadcast_from_rank0(st.param)
-            te.broadcast_from_rank0(st.buffers)
-            self.reducer = te.GradReducer(st.grad, n_buckets=3)
+            self.parallel = te.DataParallel(self.model.train_state(), n_buckets=3,
+                                            broadcast_buffers=getattr(args, 'broadcast_buffers', True))
+            self.reducer = self.parallel.reducer
             self.optimizer.grad_scale = 1.0 / self.reducer.world
 
     def model_load(self):
         args = self.args
         if os.path.exists(getattr(args, 'weight_path', '')):
-            from .predict import load_model
-            model = load_model(args.weight_path)           # weights-only form, or the reference's pickled module
-            try:
-                model_dict = torch.load(args.weight_path, map_location='cpu', weights_only=True)
-                model_dict = {k: v for k, v in model_dict.items() if k not in ('state_dict', 'meta')}
-            except Exception:
-                model_dict = torch.load(args.weight_path, map_location='cpu', weights_only=False)
-            model_dict['model'] = model
+            from .predict import load_checkpoint
+            model_dict = load_checkpoint(args.weight_path)  # weights-only form, or the reference's pickled module
             for k, v in (('epoch_finished', 0), ('optimizer_state_dict', None), ('ema_update', 0), ('standard', 0)):
                 model_dict.setdefault(k, v)
             for p in model_dict['model'].parameters():
@@ -398,18 +405,17 @@ class train_class:
         image_batch = image_batch.to(args.device, non_blocking=True)
         plan = model.train_plan(image_batch.shape[0], image_batch.shape[2])
         plan.reducer = self.reducer
-        if self.reducer is not None and getattr(args, 'broadcast_buffers', True):
-            # DistributedDataParallel's default broadcast_buffers=True (train_class.py:38-40 does not override it):
-            # before every forward the BatchNorm running statistics and counters of rank 0 replace everyone's
-            st = model.train_state()
-            te.broadcast_from_rank0(st.buffers)
-            te.broadcast_from_rank0(st.counters)
         pred = model(image_batch)
+        if self.parallel is not None:
+            # DistributedDataParallel's default broadcast_buffers=True (train_class.py:38-40 does not override it):
+            # rank 0's BatchNorm statistics and counters replace everyone's before the NEXT forward; issued here,
+            # the one collective runs behind this step's backward pass
+            self.parallel.after_forward()
         losses = self.loss(pred, screen_list, label_expend)
         self.optimizer.zero_grad()
         losses[0].backward()
-        if self.reducer is not None:
-            self.reducer.finish()
+        if self.parallel is not None:
+            self.parallel.finish()
         self.optimizer.step()
         self.optimizer = self.optimizer_adjust(self.optimizer)
         return torch.stack(losses).detach()
@@ -474,7 +480,9 @@ class train_class:
         state_dict + rebuild data, loadable with torch.load(weights_only=True)."""
         torch.save(model_dict, path)
         model = model_dict['model']
-        light = {k: v for k, v in model_dict.items() if k not in ('model', 'optimizer_state_dict')}
+        # the optimizer state is tensors and plain numbers: it stays, so that resuming from the light file
+        # continues Adam's moments and step count like the reference does (train_class.py:166-167)
+        light = {k: v for k, v in model_dict.items() if k != 'model'}
         light['state_dict'] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
         light['meta'] = model.checkpoint_meta()
         torch.save(light, os.path.splitext(path)[0] + '.weights.pt')

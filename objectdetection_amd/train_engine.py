@@ -12,6 +12,7 @@ import ctypes as C
 import math
 import os
 import sys
+import weakref
 
 import torch
 
@@ -20,6 +21,31 @@ from ._lib import lib, check
 from .engine import F32, BF16, Act, PlanBuilder, _round_up, CH_ALIGN
 
 BN_EPS, BN_MOMENTUM = 1e-3, 0.03
+
+# id(parameter) -> (weak reference to the parameter, weak reference to the FlatState that owns its storage).
+# The back-pointer must not live in Parameter.__dict__: torch pickles that dict, so torch.save(model) would drag
+# the whole flat state (parameters, gradients, Adam moments, EMA copies) into every checkpoint.
+_FLAT_OF = {}
+
+
+def _register_flat(p, state):
+    pid = id(p)
+
+    def drop(ref, pid=pid):
+        e = _FLAT_OF.get(pid)
+        if e is not None and e[0] is ref:
+            del _FLAT_OF[pid]
+    _FLAT_OF[pid] = (weakref.ref(p, drop), weakref.ref(state))
+
+
+def flat_state_of(p):
+    """The live FlatState whose flat buffers hold parameter `p`, or None (never a stale one: the entry must
+    name this very object and the state must still list it)."""
+    e = _FLAT_OF.get(id(p))
+    if e is None or e[0]() is not p:
+        return None
+    st = e[1]()
+    return st if st is not None and id(p) in st.offsets else None
 
 
 def _stream():
@@ -48,7 +74,7 @@ class FlatState:
                 view.copy_(p.data.float())
                 p.data = view
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
-                p._odamd_flat = self                   # a block asked to train on its own finds its network's storage
+                _register_flat(p, self)                # a block asked to train on its own finds its network's storage
         bufs = [b for b in model.buffers() if b.dtype.is_floating_point]
         self.buf_offsets, nb = {}, 0
         for b in bufs:
@@ -102,12 +128,14 @@ def _gloo_with_gpu_tensor(t, group=None):
     return dist.is_initialized() and dist.get_backend(group) == 'gloo' and t.is_cuda
 
 
-def broadcast_from_rank0(t, group=None):
-    """DDP's constructor broadcast (train_class.py:38-40).  RCCL takes device tensors; gloo (CPU tests and the
+def broadcast_from_rank0(t, group=None, async_op=False):
+    """DDP's broadcast of rank 0's tensors (train_class.py:38-40).  RCCL takes device tensors; gloo (CPU tests and the
     one-GPU rehearsal of the multi-rank path) is only ever given host tensors: its own staging of device
     tensors runs on internal streams and a helper thread, and a later blocking host-to-device copy of the
     same process (legacy default-stream semantics: it waits for every stream of the process) was seen to wait
-    on that machinery forever when two ranks share one GPU."""
+    on that machinery forever when two ranks share one GPU.
+    `async_op`: returns the collective's handle (its wait() orders the current stream behind it on RCCL and blocks
+    the host on gloo); the host-staged form has completed on return and returns None."""
     import torch.distributed as dist
     if _gloo_with_gpu_tensor(t, group):
         torch.cuda.current_stream().synchronize()
@@ -115,8 +143,65 @@ def broadcast_from_rank0(t, group=None):
         dist.broadcast(host, 0, group=group)
         t.copy_(host)
         torch.cuda.current_stream().synchronize()
-        return
-    dist.broadcast(t, 0, group=group)
+        return None
+    return dist.broadcast(t, 0, group=group, async_op=async_op) if async_op else dist.broadcast(t, 0, group=group)
+
+
+class DataParallel:
+    """The data-parallel wiring of train_class.py:37-40 (DistributedDataParallel, default arguments) over a FlatState:
+      * construction: rank 0's parameters, BatchNorm statistics and counters replace everyone's;
+      * every step: DDP's broadcast_buffers=True hands rank 0's buffers to all ranks before each forward.  Buffers
+        only change inside a forward, so the broadcast for step i+1 is issued right after the forward of step i:
+        the float32 statistics and the int64 counters are packed into one staging buffer (typed views of one
+        storage cannot be module buffers: torch.save refuses them), ONE non-blocking collective moves it behind the
+        backward pass, and `finish` waits for it together with the gradient buckets and unpacks;
+      * the bucketed gradient all-reduce (`reducer`, started by the backward pass).
+    """
+
+    def __init__(self, state, n_buckets=3, group=None, broadcast_buffers=True):
+        import torch.distributed as dist
+        self.state, self.group, self.broadcast_buffers = state, group, broadcast_buffers
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        fbytes = state.buffers.numel() * 4
+        self.stage = torch.zeros(fbytes + state.counters.numel() * 8, dtype=torch.uint8, device=state.param.device)
+        self.stage_f = self.stage[:fbytes].view(torch.float32)
+        self.stage_i = self.stage[fbytes:].view(torch.int64)
+        self.reducer = GradReducer(state.grad, n_buckets=n_buckets, group=group)
+        self.world = self.reducer.world
+        self.pending, self.unpack = None, False
+        self.collectives = 0            # collectives issued so far (tests and diagnostics)
+        if self.world > 1:
+            broadcast_from_rank0(state.param, group)
+            self.collectives += 1
+            self._send_buffers(False)
+            self._take_buffers()
+
+    def _send_buffers(self, async_op):
+        if self.rank == 0:
+            self.stage_f.copy_(self.state.buffers)
+            self.stage_i.copy_(self.state.counters)
+        self.pending = broadcast_from_rank0(self.stage, self.group, async_op=async_op)
+        self.collectives += 1
+        self.unpack = True
+
+    def _take_buffers(self):
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
+        if self.unpack and self.rank != 0:
+            self.state.buffers.copy_(self.stage_f)
+            self.state.counters.copy_(self.stage_i)
+        self.unpack = False
+
+    def after_forward(self):
+        if self.broadcast_buffers and self.world > 1:
+            self._send_buffers(True)
+
+    def finish(self):
+        """Waits for the buffer broadcast and every gradient bucket; returns the sum -> mean factor."""
+        self._take_buffers()
+        self.collectives += len(self.reducer.handles)
+        return self.reducer.finish()
 
 
 class GradReducer:

@@ -93,6 +93,90 @@ def test_bucketed_all_reduce_two_ranks_gloo():
     assert out[0] and out[1]
 
 
+def _parallel_rank(rank, world, port, out):
+    """One data-parallel step's collectives on host tensors: the branch a GPU run takes with RCCL (asynchronous
+    handles on the flat buffers themselves, no host staging)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from objectdetection_amd import train_engine as te
+    from objectdetection_amd.model import layer
+    torch.manual_seed(10 + rank)                       # different initial weights and statistics per rank
+    block = layer.elan(8, 16, n=1)
+    for m in block.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-1, 1)
+            m.num_batches_tracked.fill_(3 + rank)
+    state = te.FlatState(block)
+    dp = te.DataParallel(state, n_buckets=3)
+    ok = not dp.reducer.host_staged and dp.world == world
+    ref = [torch.empty_like(state.param) for _ in range(world)]
+    dist.all_gather(ref, state.param)
+    ok = ok and all(torch.equal(r, ref[0]) for r in ref)                        # constructor broadcast: parameters
+    ok = ok and int(block.cbs0.bn.num_batches_tracked) == 3                     # ... and buffers, counters included
+    # a forward changed the buffers locally; a backward filled the gradients
+    want_buf = state.buffers + 1.0                                              # what rank 0 will hold
+    state.buffers.add_(rank + 1.0)
+    state.counters.add_(rank + 1)
+    state.grad.copy_(torch.arange(state.n, dtype=torch.float32) * (rank + 1))
+    dp.after_forward()
+    for i in (2, 0, 1):
+        dp.reducer.ready(i)
+    ok = ok and len(dp.reducer.handles) == len(dp.reducer.bounds) == 3 and dp.pending is not None
+    scale = dp.finish()
+    ok = ok and dp.pending is None and dp.reducer.handles == [] and dp.collectives == 2 + 1 + 3
+    want = torch.arange(state.n, dtype=torch.float32) * sum(range(1, world + 1)) / world
+    ok = ok and bool(torch.allclose(state.grad * scale, want))
+    ok = ok and torch.equal(state.buffers, want_buf) and int(block.cbs5.bn.num_batches_tracked) == 4
+    ok = ok and torch.equal(block.cbs1.bn.running_mean, state.buffers[state.buf_names['cbs1.bn.running_mean']:][:4])
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_collectives_two_ranks_gloo_async():
+    ctx = mp.get_context('spawn')
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_parallel_rank, args=(r, 2, 29519, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out[0] and out[1]
+
+
+def test_flat_state_stays_out_of_pickles():
+    """torch.save(model) after the flat training state exists must not carry it (parameters, gradients, Adam
+    moments, EMA copies), and a reloaded module must not find a stale state."""
+    import io
+    from objectdetection_amd import train_engine as te
+    from objectdetection_amd.model.yolov7 import yolov7
+    args = patterns.default_args(input_size=64, output_class=1)
+    net = yolov7(args)
+
+    def size(m):
+        f = io.BytesIO()
+        torch.save(m, f)
+        return f.getbuffer().nbytes, f
+
+    before, _ = size(net)
+    st = net.train_state()
+    st.enable_ema()
+    p = next(net.parameters())
+    assert te.flat_state_of(p) is st and '_odamd_flat' not in p.__dict__
+    after, f = size(net)
+    assert abs(after - before) < 0.02 * before, (before, after)
+    f.seek(0)
+    twin = torch.load(f, weights_only=False)
+    assert twin._state is None
+    assert all(te.flat_state_of(q) is None and '_odamd_flat' not in q.__dict__ for q in twin.parameters())
+    # a block of the network finds the network's storage; a block on its own does not inherit anything stale
+    assert te.flat_state_of(next(net.elan4.parameters())) is st
+    assert te.flat_state_of(next(twin.elan4.parameters())) is None
+
+
 def test_bucket_plan_waits_for_every_tensor_inside_a_bucket():
     """Bucket bounds cut through tensors.  A bucket may only be reduced after the LAST tensor with any element
     in it has its gradient; a tensor that straddles a bound (here a bias forced across it) belongs to both."""
