@@ -90,46 +90,55 @@ def cpu_baseline(model, a, margs, x_cpu):
             'batch1_cpu_by_stage_us': {'C80': c80, 'C1': c1}}
 
 
-def end_to_end_leg(model, a, margs, pipe, x_cpu, steps=6):
+def end_to_end_leg(model, a, margs, x_cpu, steps=12):
     """The same step fed from the HOST and read back to the host: page-locked uint8 HWC images -> H2D ->
-    / 255 and HWC -> CHW on the device -> network -> decode / NMS -> kept rows of every image on the host
-    (what predict.py:53-58 hands back).  Reported beside `value`, never as `value`."""
+    / 255 and HWC -> CHW on the device (one launch per batch) -> network -> decode / NMS -> kept rows of every image
+    in page-locked host memory (what predict.py:53-58 hands back).  Reported beside `value`, never as `value`.
+    Batch i+1 is uploaded and enqueued before the rows of batch i are read back; two device input buffers alternate
+    (the network of batch i may still read its input while batch i+1 is being prepared)."""
     import ctypes as C
     from objectdetection_amd._lib import lib, check
+    from objectdetection_amd.postprocess import HostStager
+    from objectdetection_amd.predict import detect_pipeline
     dev = next(model.parameters()).device
     img8 = (x_cpu.permute(0, 2, 3, 1) * 255).to(torch.uint8).contiguous().pin_memory()
-    x = torch.empty((a.batch, 3, a.size, a.size), dtype=torch.float32, device=dev)
+    xs = [torch.empty((a.batch, 3, a.size, a.size), dtype=torch.float32, device=dev) for _ in range(2)]
+    d8s = [torch.empty(img8.shape, dtype=torch.uint8, device=dev) for _ in range(2)]
+    pipe = detect_pipeline(model, a.conf, a.iou, anchor=margs.anchor, input_size=a.size, reuse_outputs=3)
+    stager = HostStager(2)
+    turn = [0]
 
     def step():
-        d8 = img8.to(dev, non_blocking=True)
+        i = turn[0]
+        turn[0] ^= 1
+        d8s[i].copy_(img8, non_blocking=True)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for b in range(a.batch):
-            check(lib.odamd_preprocess_u8(d8[b].data_ptr(), a.size, a.size, x[b].data_ptr(), a.size, st), 'preprocess_u8')
-        res = pipe.submit(x)
-        return res, d8
+        check(lib.odamd_preprocess_u8_batch(d8s[i].data_ptr(), a.batch, a.size, a.size, xs[i].data_ptr(), a.size, st),
+              'preprocess_u8_batch')
+        return pipe.submit(xs[i])
 
-    pending = None
-    for i in range(2):
-        r, keep = step()
-        pipe.synchronize()
-        r.per_image()
+    def collect(res):
+        res.done.synchronize()
+        return sum(0 if r is None else len(r) for r, _ in res.to_host(stager, copy=False))
+
+    for i in range(3):
+        collect(step())
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rows_out = 0
+    rows_out, pending = 0, None
     for i in range(steps):
         cur = step()
         if pending is not None:                 # read batch i-1 back while batch i runs
-            for e in (pending[0].done if isinstance(pending[0].done, list) else [pending[0].done]):
-                e.synchronize()
-            rows_out += sum(0 if r is None else len(r) for r, _ in pending[0].per_image())
+            rows_out += collect(pending)
         pending = cur
-    pipe.synchronize()
-    rows_out += sum(0 if r is None else len(r) for r, _ in pending[0].per_image())
+    rows_out += collect(pending)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {'images_per_sec': a.batch * steps / dt, 'ms_per_step': dt / steps * 1e3, 'steps': steps,
             'h2d_bytes_per_step': int(img8.numel()), 'kept_rows_per_step': rows_out / steps,
-            'note': 'uint8 HWC host images in, kept rows on the host out; H2D + device-side /255 and transpose + D2H inside the timed region'}
+            'd2h_bytes_per_step': int(rows_out / steps * (margs.output_class + 5 + 1) * 4),
+            'note': 'uint8 HWC host images in, kept rows in page-locked host memory out; H2D + device-side /255 and '
+                    'transpose + D2H inside the timed region'}
 
 
 def dense_leg(a, dev, steps=3):
@@ -161,6 +170,55 @@ def dense_leg(a, dev, steps=3):
     return {'workload': 'YOLOv7-s 1280x1280 batch 16 bf16, C=80, conf 0.001, iou 0.5', 'network_ms_per_batch': n,
             'postprocess_ms_per_batch': p, 'ms_per_batch': n + p, 'images_per_sec': batch / ((n + p) * 1e-3),
             'decode_nms_us_per_image': p * 1e3 / batch, 'candidates_per_image': cand, 'kept_per_image': kept}
+
+
+def preset_leg(a, dev, preset='l', batch=64, steps=5):
+    """The network alone for a wider preset (model/yolov7.py:9-12: 'l' = base width 64, three 3x3 convolutions per ELAN
+    branch: 416 GFLOP per 640 x 640 image, ~500 FLOP per byte, i.e. the configuration whose convolutions are bound by
+    the matrix cores and not by HBM).  Whole forwards timed with HIP events on the launch stream, then one pass of
+    per-launch events for the family table and the per-layer bound min(MFMA, HBM)."""
+    from objectdetection_amd import engine
+    from objectdetection_amd.model.yolov7 import yolov7
+    from oracle import patterns
+    margs = patterns.default_args(input_size=a.size, output_class=a.classes, model_type=preset)
+    torch.manual_seed(999)
+    model = yolov7(margs).to(dev).eval()
+    x = torch.rand(batch, 3, a.size, a.size, generator=torch.Generator().manual_seed(999)).to(dev)
+    for _ in range(2):
+        model.head_tensors(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        model.head_tensors(x)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    prof = model._plan(x).profile(x, repeats=3)
+    peak, hbm = MFMA_PEAK_TFLOPS[a.dtype] * 1e12, HBM_PEAK_GBS * 1e9
+    flops = sum(m['flops'] for m in prof)
+    ideal = sum(max(m['flops'] / peak, m['bytes'] / hbm) for m in prof)
+    layer_ms = sum(m['ms'] for m in prof)
+    bound = [m for m in prof if m['flops'] / peak > m['bytes'] / hbm]
+    b_ms, b_fl = sum(m['ms'] for m in bound), sum(m['flops'] for m in bound)
+    fam = {}
+    for m in prof:
+        f = fam.setdefault(m['kernel'], {'ms': 0.0, 'flops': 0.0, 'launches': 0})
+        f['ms'] += m['ms']
+        f['flops'] += m['flops']
+        f['launches'] += 1
+    params = sum(p.numel() for p in model.parameters())
+    del model, x
+    return {'workload': f'YOLOv7-{preset} {a.size}x{a.size} batch {batch} {a.dtype}, network only (C={a.classes})',
+            'params': params, 'ms_per_batch': ms, 'images_per_sec': batch / (ms * 1e-3),
+            'conv_gflop_per_image': flops / batch / 1e9, 'network_tflops': flops / (ms * 1e-3) / 1e12,
+            'frac_of_mfma_peak': flops / (ms * 1e-3) / peak,
+            'frac_of_per_layer_bound': ideal * 1e3 / layer_ms,
+            'compute_bound_layers': {'launches': len(bound), 'ms': b_ms, 'tflops': b_fl / max(b_ms, 1e-9) * 1e-9,
+                                     'frac_of_mfma_peak': b_fl / max(b_ms, 1e-9) * 1e3 / peak},
+            'kernel_families': {k: {'ms': round(v['ms'], 4), 'launches': v['launches'],
+                                    'tflops': round(v['flops'] / max(v['ms'], 1e-9) * 1e-9, 1)}
+                                for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])}}
 
 
 def train_leg(a, dev, rank, world, dist, steps, warmup, amp=False):
@@ -398,9 +456,11 @@ def main():
             'kernel_families_ms': {k: round(v['ms'], 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])},
         }
         if world == 1 and not a.no_extra:
-            out['end_to_end'] = end_to_end_leg(model, a, margs, pipe, x_cpu)
+            out['end_to_end'] = end_to_end_leg(model, a, margs, x_cpu)
             torch.cuda.empty_cache()
             out['dense'] = dense_leg(a, dev)
+            torch.cuda.empty_cache()
+            out['preset_l'] = preset_leg(a, dev, 'l', batch=a.batch)
             torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(model, a, margs, x_cpu)

@@ -323,6 +323,11 @@ int odamd_detection_loss_dev(const float* pred, float* dpred, const int* screen,
  * against exact bilinear interpolation within one grey level). */
 int odamd_preprocess_u8(const uint8_t* image_hwc, int h, int w, float* out_chw, int size, void* stream);
 
+/* The same for `batch` images of one size stored back to back ((batch, h, w, 3) uint8 -> (batch, 3, size, size)
+ * float32) in ONE launch: what a batched predict (predict.py:11 parses --batch, :60-65 processes one image) feeds
+ * the network with. */
+int odamd_preprocess_u8_batch(const uint8_t* images_hwc, int batch, int h, int w, float* out_chw, int size, void* stream);
+
 /* torch_dataset label -> grid-row assignment (train_class.py:537-543 ranges = decode(-4) .. decode(+4) of
  * every grid row, :578-607 strict containment of the label's cx, cy, w, h) for a whole batch on the
  * device.  geometry: grid sizes, strides and anchors as for odamd_decode (head pointers ignored, kdim =

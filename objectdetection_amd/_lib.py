@@ -104,6 +104,7 @@ SIGNATURES = {
     'odamd_detection_loss_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                          c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     'odamd_preprocess_u8': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    'odamd_preprocess_u8_batch': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     'odamd_assign_labels': (c_int, [C.POINTER(DecodeDesc), c_float, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                     c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'odamd_adam_ema_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, C.c_double, C.c_double,

@@ -8,6 +8,18 @@
 #define ODAMD_ABI_VERSION 3
 
 #include <mutex>
+#include <type_traits>
+
+// Compile-time loop: f(std::integral_constant<int, I>) for I = FROM .. TO - 1.  `#pragma unroll` is a request that the
+// unroller drops once the unrolled body passes its size threshold; indices that must be constants (register arrays that
+// would otherwise land in private memory) are iterated with this instead.
+template <int FROM, int TO, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (FROM < TO) {
+        f(std::integral_constant<int, FROM>{});
+        static_for<FROM + 1, TO>(f);
+    }
+}
 // Raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) on the current device only when the
 // limit set so far is smaller: the attribute call is a driver round trip, and the launch paths would make it per launch.
 inline hipError_t odamd_ensure_lds(const void* kernel, size_t bytes) {

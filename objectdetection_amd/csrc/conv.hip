@@ -1680,6 +1680,7 @@ S3Config s3_config(const ConvP& p, int ks, int stride, int dtype) {
     if (dtype != ODAMD_DTYPE_BF16 || ks != 3 || p.pool || p.upz || p.nchw || p.accum || !p.scale || !p.shift) return none;
 #ifdef ODAMD_LAB
     if (g_lab_no_s3) return none;
+    if (g_lab_s3.pg && g_lab_s3.ksteps * 16 == p.Cin && g_lab_s3.cg * 32 == p.Cout && g_lab_s3.st == stride) return g_lab_s3;
 #endif
     const long long npix = (long long)p.B * p.Ho * p.Wo;
     // measured at batch 64 (tools/micro/conv_lab.hip and the per-layer profile of the network): stride 1 is ahead of

@@ -224,18 +224,16 @@ __global__ void __launch_bounds__(256) conv_s3_kernel(S3P p) {
             for (int i = 0; i < PGW; ++i) bb[slot][i] = *(const u32x4*)(buf + b_addr[i][tap] + s2 * 512);
         };
         read_group(0, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) read_group(g + 1, (g + 1) & 1);
-#pragma unroll
-            for (int k = g * MAXJ / NG; k < (g + 1) * MAXJ / NG; ++k) issue_piece(k, inc, nbuf);
-#pragma unroll
-            for (int u = g * NU / NG; u < (g + 1) * NU / NG; ++u) epi_unit(u, ap, prev);
+        static_for<0, NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g + 1 < NG) read_group(g + 1, (g + 1) & 1);
+            static_for<g * MAXJ / NG, (g + 1) * MAXJ / NG>([&](auto kc) { issue_piece(decltype(kc)::value, inc, nbuf); });
+            static_for<g * NU / NG, (g + 1) * NU / NG>([&](auto uc) { epi_unit(decltype(uc)::value, ap, prev); });
 #pragma unroll
             for (int i = 0; i < PGW; ++i)
 #pragma unroll
                 for (int jc = 0; jc < CG; ++jc) mma_step<DT>(ac[i][jc], a[g & 1][jc], bb[g & 1][i]);
-        }
+        });
         prev = cur;
         S3_STAMP(5);
     };

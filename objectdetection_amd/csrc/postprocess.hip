@@ -161,6 +161,8 @@ __global__ void __launch_bounds__(256)
 preprocess_u8_kernel(const uint8_t* __restrict__ img, int H0, int W0, float* __restrict__ out, int S) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= S * S) return;
+    img += (size_t)blockIdx.y * H0 * W0 * 3;        // image blockIdx.y of a batch of equally sized images
+    out += (size_t)blockIdx.y * 3 * S * S;
     const int dy = i / S, dx = i - dy * S;
     int x0, x1, a0, a1, y0, y1, b0, b1;
     if (W0 == S) { x0 = x1 = dx; a0 = 2048; a1 = 0; } else resize_tap(dx, (float)W0 / (float)S, W0, &x0, &x1, &a0, &a1);
@@ -1562,6 +1564,12 @@ int odamd_decode(const odamd_decode_desc* d, float* out, void* stream) {
 int odamd_preprocess_u8(const uint8_t* image_hwc, int h, int w, float* out_chw, int size, void* stream) {
     if (!image_hwc || !out_chw || h < 1 || w < 1 || size < 1 || h > 32768 || w > 32768) return ODAMD_E_ARG;
     preprocess_u8_kernel<<<(size * size + 255) / 256, 256, 0, (hipStream_t)stream>>>(image_hwc, h, w, out_chw, size);
+    return (int)hipGetLastError();
+}
+
+int odamd_preprocess_u8_batch(const uint8_t* images_hwc, int batch, int h, int w, float* out_chw, int size, void* stream) {
+    if (!images_hwc || !out_chw || batch < 1 || batch > 65535 || h < 1 || w < 1 || size < 1 || size > 32768) return ODAMD_E_ARG;
+    preprocess_u8_kernel<<<dim3((size * size + 255) / 256, batch), 256, 0, (hipStream_t)stream>>>(images_hwc, h, w, out_chw, size);
     return (int)hipGetLastError();
 }
 

@@ -25,6 +25,7 @@ from ._lib import lib, check
 F32, BF16 = 0, 1
 FUSE_MP = True                # both 1x1 convolutions of an mp block in one launch (bf16 plans)
 FUSE_FIRST2 = True     # bf16 plans run cbs0 + cbs1 as one launch when the widths are 16 and 32
+SIDE_STREAMS = True    # side branches of a plan (heads, lateral 1x1 convolutions) run on a second HIP stream
 _TORCH_DT = {0: torch.float32, 1: torch.bfloat16}
 CH_ALIGN = 16            # channel granule of buffer slices in bf16 plans (f32 plans use 8)
 
@@ -84,6 +85,21 @@ class PlanBuilder:
         self.buffers = []      # (cphys, h, w)
         self.ops = []          # dicts, resolved to launches by Plan
         self.convs = []        # ops that own packed weights
+        self._side = 0         # > 0: ops emitted now belong to a side branch (see side_branch)
+
+    def side_branch(self):
+        """Context manager: the ops emitted inside do not feed the ops that follow them directly (a branch whose
+        result is only read further down, e.g. a head or the lateral 1x1 of the neck).  An inference plan runs them
+        on a second HIP stream, beside the launches that follow in plan order, and joins before the first reader."""
+        pb = self
+
+        class _Ctx:
+            def __enter__(self):
+                pb._side += 1
+
+            def __exit__(self, *exc):
+                pb._side -= 1
+        return _Ctx()
 
     # ---- buffers -----------------------------------------------------------------------
     def buffer(self, widths, h, w):
@@ -111,7 +127,7 @@ class PlanBuilder:
         if out is None:
             out = self.single(cout, ho, wo)
         assert out.c == cout and out.h == ho and out.w == wo and x.c == mod.conv.in_channels
-        op = dict(kind='conv', mod=mod, x=x, y=out, k=k, s=s, pool=pool, act=1)
+        op = dict(kind='conv', mod=mod, x=x, y=out, k=k, s=s, pool=pool, act=1, side=self._side > 0)
         self.ops.append(op)
         self.convs.append(op)
         return out
@@ -127,7 +143,8 @@ class PlanBuilder:
 
     def head(self, mod, x):
         """head.output: 1x1 conv + bias, float32 NCHW (model/layer.py:232-235)."""
-        op = dict(kind='head', mod=mod, x=x, k=1, s=1, pool=False, act=0, cout=mod.output.out_channels)
+        op = dict(kind='head', mod=mod, x=x, k=1, s=1, pool=False, act=0, cout=mod.output.out_channels,
+                  side=self._side > 0)
         self.ops.append(op)
         self.convs.append(op)
         return op
@@ -229,6 +246,7 @@ class Plan:
             a = ops[i]
             b = ops[i + 1] if i + 1 < len(ops) else None
             if (b is not None and a['kind'] == 'conv' and b['kind'] == 'conv' and a['x'] is b['x']
+                    and a.get('side') == b.get('side')
                     and a['k'] == 1 and b['k'] == 1 and a['s'] == 1 and b['s'] == 1 and not a['pool'] and not b['pool']
                     and a['y'].buf == b['y'].buf and a['y'].c == a['y'].cphys and len(b['y'].segments) == 1
                     and b['y'].c0 == a['y'].c0 + a['y'].cphys):
@@ -262,6 +280,7 @@ class Plan:
             a = ops[i]
             b = ops[i + 1] if i + 1 < len(ops) else None
             if (b is not None and a['kind'] == 'conv' and b['kind'] == 'conv' and a['x'] is b['x'] and 'mods' not in a
+                    and not a.get('side') and not b.get('side')
                     and 'mods' not in b and a['k'] == 1 and b['k'] == 1 and a['s'] == 1 and b['s'] == 1 and a['pool']
                     and not b['pool'] and len(a['y'].segments) == 1 and len(b['y'].segments) == 1
                     and a['y'].c == a['y'].cphys and b['y'].c == b['y'].cphys):
@@ -389,6 +408,7 @@ class Plan:
     def _build(self):
         b, dev, dt = self.b, self.b.device, _TORCH_DT[self.b.dtype]
         B = b.batch
+        self.launch_op = []     # launch index -> the op it belongs to
         for op in b.ops:
             kind = op['kind']
             if kind in ('conv', 'head'):
@@ -406,9 +426,12 @@ class Plan:
                         bytes=ma['bytes'] + mb['bytes'] - float(B * x.h * x.w * op['plain']['mod'].conv.in_channels * self.es),
                         shape=mb['shape'] + '+' + ma['shape'].split(' ')[1] + ' pooled')
                 else:
-                    for d, meta in ((da, ma), (db, mb)):
+                    # two launches: the pooled branch is a side branch (only the block's consumer reads its result)
+                    op['pooled']['side'] = True
+                    for d, meta, sub in ((da, ma, op['pooled']), (db, mb, op['plain'])):
                         self.launches.append((lib.odamd_conv_forward, [C.byref(d)], 'conv', None))
                         self.meta[len(self.launches) - 1] = meta
+                        self.launch_op.append(sub)
             elif kind == 'first':
                 m, y = op['mod'], op['y']
                 cout = m.conv.out_channels
@@ -465,12 +488,56 @@ class Plan:
                     dst += n
             else:
                 raise AssertionError(kind)
+            self.launch_op += [op] * (len(self.launches) - len(self.launch_op))
+        self._plan_streams()
+
+    def _plan_streams(self):
+        """Side branches (PlanBuilder.side_branch) run on a second stream.  Per launch: 0 = main stream, 1 = side stream;
+        `fork[i]`: the side stream first waits for everything enqueued on the main stream so far; `join[i]`: the main
+        stream first waits for the side stream (launch i reads what a side launch wrote).  The side stream is joined at
+        the end of a run as well, so consecutive runs of one plan never overlap."""
+        n = len(self.launches)
+        self.lane = [1 if SIDE_STREAMS and self.launch_op[i].get('side') else 0 for i in range(n)]
+        self.fork, self.join = [False] * n, [False] * n
+        pending = []          # (buf, lo, hi) ranges written by side launches that the main stream has not joined
+        prev = 0
+        for i in range(n):
+            op = self.launch_op[i]
+            if self.lane[i]:
+                self.fork[i] = prev == 0
+                if op['kind'] != 'head':
+                    y = op['y']
+                    pending.append((y.buf, y.c0, y.c0 + y.cphys))
+            else:
+                reads = [op[k] for k in ('x',) if op.get(k) is not None]
+                if op['kind'] == 'mp2':
+                    reads = [op['plain']['x']]
+                writes = [op[k] for k in ('y',) if op.get(k) is not None] + list(op.get('ys', []))
+                if op['kind'] == 'mp2':
+                    writes = [op['pooled']['y'], op['plain']['y']]
+                for a in reads + writes:
+                    if any(bf == a.buf and lo < a.c0 + a.cphys and a.c0 < hi for bf, lo, hi in pending):
+                        self.join[i] = True
+                        pending = []
+                        break
+            prev = self.lane[i]
+        self.has_side = any(self.lane)
+        self._side_stream = None
+        self._events = []
 
     def run(self, image):
         """Enqueue the whole plan on the current stream. `image`: contiguous float32 NCHW."""
         self.refresh_weights()
-        st = _stream()
+        main = torch.cuda.current_stream()
+        st = C.c_void_p(main.cuda_stream)
+        side = side_st = None
+        if self.has_side:
+            if self._side_stream is None or self._side_stream.device != main.device:
+                self._side_stream = torch.cuda.Stream(device=main.device)
+            side = self._side_stream
+            side_st = C.c_void_p(side.cuda_stream)
         img = image.data_ptr()
+        nev, side_busy = 0, False
         for i, (fn, args, name, image_slot) in enumerate(self.launches):
             if name == 'copy':
                 x, y = args
@@ -478,10 +545,26 @@ class Plan:
                 continue
             if image_slot is not None:
                 args[image_slot] = img
-            rc = fn(*args, st)
+            if self.fork[i] or (self.join[i] and side_busy):
+                if nev == len(self._events):
+                    self._events.append(torch.cuda.Event())
+                ev = self._events[nev]
+                nev += 1
+                if self.fork[i]:
+                    ev.record(main)
+                    side.wait_event(ev)
+                else:
+                    ev.record(side)
+                    main.wait_event(ev)
+                    side_busy = False
+            if self.lane[i]:
+                side_busy = True
+            rc = fn(*args, side_st if self.lane[i] else st)
             if rc:
                 m = self.meta.get(i, {})
                 check(rc, f"{name} #{i} {m.get('kernel', '')} {m.get('shape', '')}")
+        if side_busy:
+            main.wait_stream(side)
         return self.finish(self, image) if self.finish else self.outputs.get('nchw')
 
     def profile(self, image, repeats=3):

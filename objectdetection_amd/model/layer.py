@@ -188,7 +188,8 @@ class sppcspc(_Block):  # in_ -> out_, same spatial size
         w3 = _w(self.cbs3)
         cat10, (main, side) = pb.buffer([_w(self.cbs9), _w(self.cbs0)], x.h, x.w)
         cat7, pyramid = pb.buffer([w3] * 4, x.h, x.w)
-        self.cbs0._emit(pb, x, side)
+        with pb.side_branch():                            # only cbs11 reads it: beside the cbs1 .. cbs9 chain
+            self.cbs0._emit(pb, x, side)
         t = self.cbs2._emit(pb, self.cbs1._emit(pb, x))
         self.cbs3._emit(pb, t, pyramid[0])
         pb.spp(pyramid[0], pyramid[1:])                   # 5/9/13 pools of the SAME tensor

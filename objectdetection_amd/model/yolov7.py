@@ -125,26 +125,33 @@ class yolov7(torch.nn.Module):
         x = self.mp5._emit(pb, self.elan4._emit(pb, x))
         l6 = self.elan6._emit(pb, x)
         l8 = self.elan8._emit(pb, self.mp7._emit(pb, l6))
+        # The lateral 1x1 convolutions of the neck (l8_concat, l6_concat) only need l8 / l6, and nothing reads their
+        # results before elan_h15 / elan_h19: they are emitted here, as a side branch that runs beside the 20 x 20
+        # section of the network (launch-latency bound chains that leave most of the chip idle).
+        cat14, (up13, l8c) = pb.buffer([_w(self.cbs12), _w(self.l8_concat)], l8.h, l8.w)
+        cat18, (up17, l6c) = pb.buffer([_w(self.cbs16), _w(self.l6_concat)], l6.h, l6.w)
+        with pb.side_branch():
+            self.l8_concat._emit(pb, l8, l8c)
+            self.l6_concat._emit(pb, l6, l6c)
         x = self.elan10._emit(pb, self.mp9._emit(pb, l8))
         # concat24 = [mp23 | l11], concat21 = [mp20 | l15]: the late consumers' buffers exist first,
         # so sppcspc11 / elan_h15 store their result where concat24 / concat21 will read it.
         cat24, (m23a, m23b, l11) = pb.buffer([_w(self.mp23.cbs1), _w(self.mp23.cbs3), _w(self.sppcspc11)], x.h, x.w)
         self.sppcspc11._emit(pb, x, l11)
         t = self.cbs12._emit(pb, l11)
-        cat14, (up13, l8c) = pb.buffer([_w(self.cbs12), _w(self.l8_concat)], l8.h, l8.w)
         pb.upsample2(t, up13)
-        self.l8_concat._emit(pb, l8, l8c)
         cat21, (m20a, m20b, l15) = pb.buffer([_w(self.mp20.cbs1), _w(self.mp20.cbs3), _w(self.elan_h15)], l8.h, l8.w)
         self.elan_h15._emit(pb, cat14, l15)
         t = self.cbs16._emit(pb, l15)
-        cat18, (up17, l6c) = pb.buffer([_w(self.cbs16), _w(self.l6_concat)], l6.h, l6.w)
         pb.upsample2(t, up17)
-        self.l6_concat._emit(pb, l6, l6c)
         x = self.elan_h19._emit(pb, cat18)
-        heads = [pb.head(self.head0, x)]
+        # the heads feed nothing inside the network: side branches, joined when the plan ends
+        with pb.side_branch():
+            heads = [pb.head(self.head0, x)]
         self.mp20._emit(pb, x, (m20a, m20b))
         x = self.elan_h22._emit(pb, cat21)
-        heads.append(pb.head(self.head1, x))
+        with pb.side_branch():
+            heads.append(pb.head(self.head1, x))
         self.mp23._emit(pb, x, (m23a, m23b))
         x = self.elan_h25._emit(pb, cat24)
         heads.append(pb.head(self.head2, x))

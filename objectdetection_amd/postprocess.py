@@ -70,26 +70,75 @@ def decode_backward(heads, input_size, anchor, grad_out):
     return grads
 
 
+class HostStager:
+    """Page-locked host buffers for the kept rows of whole batches, `slots` of them used in turn: a device-to-host
+    copy from pageable memory runs at a fraction of the link rate and blocks, one into page-locked memory is
+    asynchronous and runs at the link rate.  Arrays handed out without a copy are views of a slot: they stay valid
+    until the slot comes round again (`slots` calls later)."""
+
+    def __init__(self, slots=2):
+        self.slots = [None] * slots
+        self.turn = 0
+
+    def take(self, n_rows, kdim, batch):
+        i = self.turn
+        self.turn = (i + 1) % len(self.slots)
+        s = self.slots[i]
+        if s is None or s['rows'].shape[0] < n_rows or s['rows'].shape[1] != kdim or s['cnt'].shape[0] < batch:
+            cap = max(4096, int(n_rows * 1.5))
+            s = self.slots[i] = dict(rows=torch.empty((cap, kdim), dtype=torch.float32).pin_memory(),
+                                     idx=torch.empty(cap, dtype=torch.int32).pin_memory(),
+                                     sel=torch.empty(cap, dtype=torch.int64).pin_memory(),
+                                     cnt=torch.empty(max(batch, 64), dtype=torch.int32).pin_memory())
+        return s
+
+
+_default_stager = HostStager(2)
+
+
 class PostResult:
     """Device-side result of a batched post-processing call."""
 
     def __init__(self, rows, idx, count, cand):
         self.rows, self.idx, self.count, self.cand = rows, idx, count, cand
 
-    def per_image(self):
-        """Host copy: list of (rows ndarray (kept,K) or None, kept row indices ndarray).  Only the kept rows
-        cross to the host (the device buffers are sized for the worst case: every row kept)."""
-        cnt = [min(n, self.idx.shape[1]) for n in self.count.cpu().tolist()]
-        if sum(cnt) == 0:
-            return [(None, np.zeros((0,), np.int64)) for _ in cnt]
-        # two device-side gathers and two copies for the whole batch
-        rows = torch.cat([self.rows[b, :n] for b, n in enumerate(cnt)]).cpu().numpy()
-        idx = torch.cat([self.idx[b, :n] for b, n in enumerate(cnt)]).cpu().numpy().astype('int64')
+    def to_host(self, stager=None, copy=True):
+        """Host copy: list of (rows ndarray (kept,K) or None, kept row indices ndarray int32).  Only the kept rows
+        cross to the host (the device buffers are sized for the worst case): the counts come first (one small
+        synchronising copy), then ONE device-side gather of the kept rows of all images and two asynchronous copies
+        into page-locked staging.  copy=False returns views of the staging slot (see HostStager)."""
+        stager = stager or _default_stager
+        b, max_keep, k = self.rows.shape
+        s = stager.take(0, k, b) if stager.slots[stager.turn] is not None else stager.take(4096, k, b)
+        s['cnt'][:b].copy_(self.count, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        cnt = np.minimum(s['cnt'][:b].numpy(), max_keep)
+        total = int(cnt.sum())
+        if total == 0:
+            return [(None, np.zeros((0,), np.int32)) for _ in range(b)]
+        if s['rows'].shape[0] < total:
+            stager.turn = (stager.turn - 1) % len(stager.slots)         # grow this slot in place
+            s = stager.take(total, k, b)
+        starts = np.arange(b, dtype=np.int64) * max_keep
+        offs = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+        sel = np.repeat(starts - offs, cnt) + np.arange(total, dtype=np.int64)     # flat (image, slot) index of every kept row
+        s['sel'][:total].copy_(torch.from_numpy(sel))
+        sel_dev = s['sel'][:total].to(self.rows.device, non_blocking=True)
+        s['rows'][:total].copy_(self.rows.view(b * max_keep, k).index_select(0, sel_dev), non_blocking=True)
+        s['idx'][:total].copy_(self.idx.view(-1).index_select(0, sel_dev), non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        rows, idx = s['rows'][:total].numpy(), s['idx'][:total].numpy()
+        if copy:
+            rows, idx = rows.copy(), idx.copy()
         out, o = [], 0
-        for n in cnt:
+        for n in cnt.tolist():
             out.append((rows[o:o + n] if n else None, idx[o:o + n]))
             o += n
         return out
+
+    def per_image(self):
+        """Host copy with arrays of their own: list of (rows ndarray (kept,K) or None, kept row indices int64)."""
+        return [(r, i.astype('int64')) for r, i in self.to_host(copy=True)]
 
 
 _ws_cache = {}
@@ -130,14 +179,19 @@ def postprocess(pred, confidence_threshold, iou_threshold, scale_xy=None, max_ke
 
 
 def postprocess_heads(heads, input_size, anchor, confidence_threshold, iou_threshold, scale_xy=None, max_keep=None,
-                      n_pad=0):
-    """Same chain straight from the raw heads; the (B,R,K) tensor is never materialised."""
+                      n_pad=0, outputs=None):
+    """Same chain straight from the raw heads; the (B,R,K) tensor is never materialised.
+    `outputs`: (rows, idx, count, cand) tensors of an earlier call with the same sizes to write into (a serving loop
+    that has consumed that result), instead of new ones."""
     d = decode_desc(heads, input_size, anchor, True)
     r = sum(h.shape[1] * h.shape[2] * h.shape[3] for h in heads)
     max_keep = max_keep or r
     dev = heads[0].device
     ws = _workspace(lib.odamd_postprocess_workspace_bytes(d.batch, r, d.kdim, n_pad), dev)
-    rows, idx, cnt, cand = _outputs(d.batch, d.kdim, max_keep, dev)
+    if outputs is not None and tuple(outputs[0].shape) == (d.batch, max_keep, d.kdim):
+        rows, idx, cnt, cand = outputs
+    else:
+        rows, idx, cnt, cand = _outputs(d.batch, d.kdim, max_keep, dev)
     check(lib.odamd_postprocess_heads(C.byref(d), float(confidence_threshold), float(iou_threshold), _ptr(scale_xy),
                                       n_pad, _ptr(rows), _ptr(idx), _ptr(cnt), _ptr(cand), max_keep, _ptr(ws),
                                       ws.numel(), _stream()), 'postprocess_heads')

@@ -201,8 +201,14 @@ class detect_pipeline:
         pipe.synchronize()                                      # results' tensors are now final
     """
 
-    def __init__(self, model, confidence_threshold, iou_threshold, anchor=None, input_size=None, splits=1):
+    def __init__(self, model, confidence_threshold, iou_threshold, anchor=None, input_size=None, splits=1, max_keep=None,
+                 reuse_outputs=0):
+        """`max_keep`: bound of kept rows per image (sizes the output buffers; default: every row).
+        `reuse_outputs` = n > 0: the result tensors of a submit are written over by the n-th submit after it (a
+        serving loop that has read a result by then), instead of allocating (batch, max_keep, K) per submit."""
         self.model = model
+        self.max_keep, self.reuse_outputs = max_keep, reuse_outputs
+        self._outs, self._out_turn = {}, 0
         self.conf, self.iou = confidence_threshold, iou_threshold
         self.anchor = anchor if anchor is not None else model.decode.anchor
         self.input_size = input_size if input_size is not None else model.decode.input_size
@@ -237,12 +243,18 @@ class detect_pipeline:
                 ready.record(net)
             with torch.cuda.stream(post):
                 post.wait_event(ready)
-                res = _post.postprocess_heads(heads, self.input_size, self.anchor, self.conf, self.iou, sc)
+                outs = self._outs.get((self._out_turn, s)) if self.reuse_outputs else None
+                res = _post.postprocess_heads(heads, self.input_size, self.anchor, self.conf, self.iou, sc,
+                                              max_keep=self.max_keep, outputs=outs)
+                if self.reuse_outputs:
+                    self._outs[(self._out_turn, s)] = (res.rows, res.idx, res.count, res.cand)
                 done = torch.cuda.Event()
                 done.record(post)
             self.heads_free[(slot, s)] = done
             res.done = done
             parts.append(res)
+        if self.reuse_outputs:
+            self._out_turn = (self._out_turn + 1) % self.reuse_outputs
         return parts[0] if n == 1 else PostResultList(parts)
 
     def synchronize(self):

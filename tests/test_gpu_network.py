@@ -217,6 +217,8 @@ def test_network_640_bf16_vs_f32_oracle(od):
         assert got.shape == (4, 25200, 85)
         assert rel_err(got[..., :4], ref[..., :4]) < TOL[dtype], (dtype, rel_err(got[..., :4], ref[..., :4]))
         assert rel_err(got[..., 4:], ref[..., 4:]) < TOL[dtype], (dtype, rel_err(got[..., 4:], ref[..., 4:]))
+        assert_elementwise(got[..., :4], ref[..., :4], TOL[dtype])
+        assert_elementwise(got[..., 4:], ref[..., 4:], TOL[dtype])
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
@@ -397,6 +399,8 @@ def test_pruned_network_vs_reference_fixture(od, golden):
     got = net.cuda().eval()(patterns.image_batch(2, 64).cuda()).cpu().numpy()
     assert rel_err(got[..., :4], g['eval'][..., :4]) < TOL['f32']
     assert rel_err(got[..., 4:], g['eval'][..., 4:]) < TOL['f32']
+    assert_elementwise(got[..., :4], g['eval'][..., :4], TOL['f32'])
+    assert_elementwise(got[..., 4:], g['eval'][..., 4:], TOL['f32'])
 
 
 @pytest.mark.parametrize('c,ld,dt', [(3, 8, 'f32'), (3, 8, 'bf16'), (8, 8, 'bf16'), (1, 8, 'f32'), (5, 16, 'bf16'), (3, 4, 'f32')])

@@ -139,6 +139,43 @@ def test_device_preprocess_matches_restated_cv2_resize(h, w, size):
     assert np.abs(want.astype(np.float64) - ref).max() <= 1.0
 
 
+def test_batched_preprocess_and_host_staging():
+    """odamd_preprocess_u8_batch == odamd_preprocess_u8 per image, bit for bit; PostResult.to_host (one gather, page-locked
+    staging) hands back exactly the rows and indices of the device result, as views or as copies."""
+    import torch
+    from objectdetection_amd import postprocess as post
+    from objectdetection_amd._lib import lib, check
+    rng = np.random.default_rng(3)
+    b, h, w, size = 5, 70, 90, 64
+    imgs = torch.from_numpy(rng.integers(0, 256, (b, h, w, 3), dtype=np.uint8)).cuda()
+    one = torch.empty((b, 3, size, size), dtype=torch.float32, device='cuda')
+    for i in range(b):
+        check(lib.odamd_preprocess_u8(imgs[i].data_ptr(), h, w, one[i].data_ptr(), size, None))
+    allb = torch.empty_like(one)
+    check(lib.odamd_preprocess_u8_batch(imgs.data_ptr(), b, h, w, allb.data_ptr(), size, None))
+    torch.cuda.synchronize()
+    assert torch.equal(one, allb)
+    # synthetic deployed predictions: image 2 keeps nothing
+    r, k = 500, 9
+    pred = torch.from_numpy(rng.random((b, r, k), dtype=np.float32))
+    pred[..., 0:2] = pred[..., 0:2] * 300 + 50
+    pred[..., 2:4] = pred[..., 2:4] * 40 + 5
+    pred[2, :, 4] = 0.0
+    res = post.postprocess(pred.cuda(), 0.5, 0.5)
+    cnt = res.count.cpu().tolist()
+    assert cnt[2] == 0 and sum(cnt) > 0
+    stager = post.HostStager(2)
+    for copy in (False, True):
+        host = res.to_host(stager, copy=copy)
+        for i, (rows, idx) in enumerate(host):
+            assert (rows is None) == (cnt[i] == 0) and len(idx) == cnt[i]
+            if cnt[i]:
+                assert np.array_equal(rows, res.rows[i, :cnt[i]].cpu().numpy())
+                assert np.array_equal(idx, res.idx[i, :cnt[i]].cpu().numpy())
+    legacy = res.per_image()
+    assert all(np.array_equal(a[1], b_[1]) for a, b_ in zip(legacy, host)) and legacy[0][1].dtype == np.int64
+
+
 def test_checkpoint_round_trip_train_to_predict(tmp_path):
     """run.py-style training writes a checkpoint; predict_class loads it (pickled module, as
     predict.py:29-30 does) and predicts on an image of another size (device-side resize)."""

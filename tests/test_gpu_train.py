@@ -255,11 +255,72 @@ def test_whole_network_train_step_bf16(te, size, batch):
              gpu_cos=cos(ga, g64), emu_cos=cos(gq, g64), gpu_vs_emu_cos=cos(ga, gq),
              gpu_norm=float(np.linalg.norm(ga) / np.linalg.norm(g64)), emu_norm=float(np.linalg.norm(gq) / np.linalg.norm(g64)))
     print(f'bf16 whole network {size}x{size} b{batch}:', {k: round(v, 4) for k, v in m.items()}, 'loss', loss, loss64, lossq)
-    np.testing.assert_allclose(loss, loss64, rtol=5e-2)
-    assert m['gpu_logits'] <= 1.5 * m['emu_logits'] + 0.02, m
-    assert m['gpu_boxes'] <= 1.5 * m['emu_boxes'] + 0.02, m
-    assert m['gpu_cos'] >= m['emu_cos'] - 0.15, m
-    assert abs(m['gpu_norm'] - 1) <= abs(m['emu_norm'] - 1) + 0.15, m
+    # Measured on MI355X (128 x 128 / 256 x 256): logits rms 0.276 / 0.259 against the emulation's 0.262 / 0.251, boxes
+    # 0.033 / 0.026 against 0.027 / 0.026, gradient cosine 0.569 / 0.590 against 0.642 / 0.633, gradient norm ratio
+    # 0.961 / 0.972 against 1.057 / 0.914, loss terms within 1.2e-3 / 5.5e-3 / 3e-3 / 1.4e-2 of fp64.  The bars are
+    # those values with about 30 % of margin (any change of a rounding moves them by a few per cent).
+    np.testing.assert_allclose(loss, loss64, rtol=2e-2)
+    assert m['gpu_logits'] <= 1.25 * m['emu_logits'], m
+    assert m['gpu_boxes'] <= 1.5 * m['emu_boxes'] + 0.003, m
+    assert m['gpu_cos'] >= m['emu_cos'] - 0.10, m
+    assert abs(m['gpu_norm'] - 1) <= 0.06, m
+
+
+def test_whole_network_train_step_640_f32(te):
+    """One float32 training step at the full input size (640 x 640, batch 4, 5 classes, random initialisation under a
+    seed, synthetic labels): prediction, the loss 4-tuple and every parameter gradient against the fp64 CPU oracle of
+    the same step.  The bar is the one of the 128 x 128 fixture test: the kernels' error against fp64 may be at most
+    NOISE_FACTOR x the error of the oracle evaluated in float32 (plain torch CPU arithmetic, i.e. what the reference
+    computes) against fp64, + 1e-4."""
+    from objectdetection_amd.model.yolov7 import yolov7
+    from objectdetection_amd.train_class import synthetic_dataset
+    from oracle import network
+    size, batch, ncls = 640, 4, 5
+    args = patterns.default_args(input_size=size, output_class=ncls)
+    torch.manual_seed(640)
+    net = yolov7(args)
+    ds = synthetic_dataset(args, batch, seed=11)
+    image, screen, expend, _ = ds.collate_fn([ds[i] for i in range(batch)])
+
+    def oracle(dt):
+        sd = {k: (v.detach().to(dt).clone().requires_grad_(True) if k.endswith(('weight', 'bias'))
+                  else (v.detach().to(dt) if v.dtype.is_floating_point else v.detach().clone()))
+              for k, v in net.state_dict().items()}
+        p = network.yolov7_forward(sd, image.to(dt), args, training=True)
+        vals = otrain.detection_loss(p, screen, expend.to(dt), args.label_smooth, ncls)
+        vals[0].backward()
+        return (p.detach().double().numpy(), np.array([float(v.detach()) for v in vals]),
+                {n: sd[n].grad.double().numpy() for n, _ in net.named_parameters()})
+
+    p64, loss64, g64 = oracle(torch.float64)
+    p32, loss32, g32 = oracle(torch.float32)
+    net = net.cuda().train()
+    state = te.FlatState(net)
+    plan = te.TrainPlan(net, state, batch, size)
+    x = image.cuda()
+    pred = plan.forward(x).cpu().numpy()
+    loss = plan.loss(screen, expend, args.label_smooth).cpu().numpy()
+    state.grad.zero_()
+    plan.backward(x)
+    torch.cuda.synchronize()
+    for sl, what in ((slice(0, 4), 'boxes'), (slice(4, None), 'logits')):
+        e_gpu, e_ref = rel_err(pred[..., sl], p64[..., sl]), rel_err(p32[..., sl], p64[..., sl])
+        print('640 forward', what, 'gpu-vs-f64', e_gpu, 'f32-oracle-vs-f64', e_ref)
+        assert e_gpu <= NOISE_FACTOR * e_ref + 1e-4, what
+    print('640 loss', loss, loss64, loss32)
+    np.testing.assert_allclose(loss, loss64, rtol=1e-4 + NOISE_FACTOR * float(np.abs(loss32 / loss64 - 1).max()))
+    worst_gpu = worst_ref = 0.0
+    for n, p in net.named_parameters():
+        e_gpu, e_ref = rel_err(p.grad.cpu().numpy(), g64[n]), rel_err(g32[n], g64[n])
+        worst_gpu, worst_ref = max(worst_gpu, e_gpu), max(worst_ref, e_ref)
+    ga = np.concatenate([p.grad.double().cpu().numpy().ravel() for _, p in net.named_parameters()])
+    gf = np.concatenate([g64[n].ravel() for n, _ in net.named_parameters()])
+    gr = np.concatenate([g32[n].ravel() for n, _ in net.named_parameters()])
+    n_gpu, n_ref = abs(np.linalg.norm(ga) / np.linalg.norm(gf) - 1), abs(np.linalg.norm(gr) / np.linalg.norm(gf) - 1)
+    print('640 gradients: worst per-parameter error gpu', worst_gpu, 'f32 oracle', worst_ref, ' norm error gpu', n_gpu,
+          'f32 oracle', n_ref)
+    assert worst_gpu <= NOISE_FACTOR * worst_ref + 1e-4
+    assert n_gpu <= NOISE_FACTOR * n_ref + 1e-4
 
 
 @pytest.mark.parametrize('cin,cout,k,s,h,w,b', [

@@ -10,7 +10,9 @@
     ODAMD_DMA_CASE(1, 8, 4, 4, 2, 64, 3) ODAMD_DMA_CASE(1, 8, 8, 4, 2, 64, 2) ODAMD_DMA_CASE(1, 8, 4, 4, 2, 128, 2)
 #define LAB_S3_VARIANTS \
     ODAMD_S3_CASE(2, 1, 1, 4, 256, 3) ODAMD_S3_CASE(2, 1, 1, 4, 256, 4) ODAMD_S3_CASE(2, 1, 1, 8, 384, 3) \
-    ODAMD_S3_CASE(2, 2, 2, 4, 640, 2)
+    ODAMD_S3_CASE(2, 2, 2, 4, 640, 2) ODAMD_S3_CASE(4, 2, 1, 4, 256, 2) ODAMD_S3_CASE(4, 2, 1, 4, 192, 3) \
+    ODAMD_S3_CASE(4, 2, 1, 4, 192, 2) ODAMD_S3_CASE(4, 1, 1, 4, 256, 2) ODAMD_S3_CASE(4, 1, 1, 4, 192, 3) \
+    ODAMD_S3_CASE(4, 1, 1, 8, 384, 2)
 #define LAB_DMA_S2_VARIANTS ODAMD_DMA_S2_CASE(8, 2, 4, 1, 32, 2) ODAMD_DMA_S2_CASE(4, 2, 4, 1, 32, 3) ODAMD_DMA_S2_CASE(4, 2, 4, 1, 64, 2) ODAMD_DMA_S2_CASE(4, 2, 2, 2, 32, 2)
 #define LAB_WRES_VARIANTS ODAMD_WRES_CASE(1, 2, 4) ODAMD_WRES_CASE(1, 1, 4) ODAMD_WRES_CASE(1, 2, 2) ODAMD_WRES_CASE(2, 2, 2) ODAMD_WRES_CASE(2, 1, 4) ODAMD_WRES_CASE(2, 1, 2)
 #include "../../objectdetection_amd/csrc/conv.hip"
@@ -48,11 +50,17 @@ int main(int argc, char** argv) {
         {"1x1 256->256 @20", 20, 256, 256, 1, 1, 0},
         {"3x3s2 64->64 @160", 160, 64, 64, 3, 2, 0},   {"3x3s2 128->128 @80", 80, 128, 128, 3, 2, 0},
         {"3x3s2 64->64 @80", 80, 64, 64, 3, 2, 0},
+        {"3x3 64->32 @80", 80, 64, 32, 3, 1, 0},
     };
     const int only = argc > 1 ? atoi(argv[1]) : -1;
+    S3Config s3_env = {};       // LAB_S3="ksteps,cg,st,pg,npad,nbuf": the persistent 3x3 kernel instantiation to force
+    if (const char* e = getenv("LAB_S3"))
+        sscanf(e, "%d,%d,%d,%d,%d,%d", &s3_env.ksteps, &s3_env.cg, &s3_env.st, &s3_env.pg, &s3_env.npad_max, &s3_env.nbuf);
     const int ldmul = argc > 2 ? atoi(argv[2]) : 1;      // x_ld = ldmul * cin, y_ld = ldmul * cout (slices of wider tensors)
     size_t max_in = 0, max_out = 0, max_w = 0;
-    for (auto& c : cases) {
+    for (size_t ci = 0; ci < cases.size(); ++ci) {
+        const Case& c = cases[ci];
+        if (argc > 1 && atoi(argv[1]) >= 0 && (int)ci != atoi(argv[1])) continue;      // buffers for the selected case only
         const int ho = c.pool ? c.h / 2 : (c.s == 2 ? c.h / 2 : c.h);
         max_in = std::max(max_in, (size_t)B * c.h * c.h * c.cin);
         max_out = std::max(max_out, (size_t)B * ho * ho * c.cout);
@@ -67,9 +75,10 @@ int main(int argc, char** argv) {
     hipMalloc(&sh, 4096 * 4);
     {
         std::vector<uint16_t> hx(max_in * ldmul), hw(max_w);
-        srand(1);
-        for (auto& v : hx) v = bf((rand() % 2001 - 1000) * 1e-3f);
-        for (auto& v : hw) v = bf((rand() % 2001 - 1000) * 3e-5f);
+        uint32_t seed = 12345u;
+        auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (int)((seed >> 8) % 2001u) - 1000; };
+        for (auto& v : hx) v = bf(rnd() * 1e-3f);
+        for (auto& v : hw) v = bf(rnd() * 3e-5f);
         hipMemcpy(x, hx.data(), max_in * 2 * ldmul, hipMemcpyHostToDevice);
         hipMemcpy(w, hw.data(), max_w * 2, hipMemcpyHostToDevice);
         std::vector<float> one(4096, 1.0f), zero(4096, 0.01f);
@@ -129,7 +138,7 @@ int main(int argc, char** argv) {
         double best = us;
         for (const DmaConfig& v : variants) {
             if (v.ks > 0 && (v.ks != c.k || c.s != (v.st == 2 ? 2 : 1) || c.pool)) continue;
-            if (v.ks > 0 && only < 0) continue;     // the full sweep only with a case selected
+            if (v.ks > 0 && (only < 0 || getenv("LAB_QUICK"))) continue;     // the full sweep only with a case selected
             g_lab_s3 = {};
             g_lab_no_wres = 0;
             g_lab_wres = {};
@@ -143,6 +152,7 @@ int main(int argc, char** argv) {
                 g_lab_s3 = {2, c.s, c.s, v.pg, v.cg, v.wp};
             } else
             g_lab_force = v;
+            if (v.ks == 0) g_lab_s3 = s3_env;
             int G = 0, CB = 0;
             if (v.ks > 0) g_lab_no_wres = 1;
             if (!odamd_conv_weight_layout(&d, &G, &CB)) { g_lab_force = {}; g_lab_s3 = {}; g_lab_no_wres = 0; g_lab_wres = {}; continue; }

@@ -1,0 +1,41 @@
+"""Whole forwards back to back (HIP events around N of them), with and without the side-branch stream; and the
+pipelined detection step with both settings."""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from objectdetection_amd import engine
+from objectdetection_amd.model.yolov7 import yolov7
+from objectdetection_amd.predict import detect_pipeline
+from oracle import patterns
+
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+args = patterns.default_args(input_size=640, output_class=80)
+engine.set_compute_dtype('bf16')
+x = torch.rand(batch, 3, 640, 640).cuda()
+for side in (False, True, False, True):
+    engine.SIDE_STREAMS = side
+    torch.manual_seed(999)
+    m = yolov7(args).cuda().eval()
+    for _ in range(5):
+        m.head_tensors(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(50):
+        m.head_tensors(x)
+    e1.record()
+    torch.cuda.synchronize()
+    net = e0.elapsed_time(e1) / 50
+    pipe = detect_pipeline(m, 0.5, 0.5, anchor=args.anchor, input_size=640)
+    for _ in range(5):
+        pipe.submit(x)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(50):
+        pipe.submit(x)
+    pipe.synchronize()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f'side streams {side}: network alone {net:.3f} ms per forward, pipelined step {e0.elapsed_time(e1) / 50:.3f} ms', flush=True)
+    del m, pipe
