@@ -938,6 +938,93 @@ conv_first_kernel(const float* __restrict__ img, const float* __restrict__ w, co
     }
 }
 
+// First layer with 32 or 64 output channels (the wider presets), bf16: same staging and gather as conv_first_kernel, but
+// all NQ = Cout / 16 matrix instructions of a pixel row share ONE gathered and converted B operand, and the rows of the
+// weight operand are dealt so that lane group kg ends up with the 4 * NQ CONSECUTIVE channels [4 NQ kg, 4 NQ (kg + 1))
+// of its pixel: row m of instruction q is channel 4 NQ (m / 4) + 4 q + m % 4.  The four lanes of a pixel then store one
+// contiguous run of 64 / 128 bytes with 16-byte stores (conv_first_kernel writes 8-byte pieces of 32-byte runs, one
+// pass over the tile per 16 channels: 3 -> 64 at 640 x 640, batch 64, ran at 1.4 TB/s).
+template <int NQ>
+__global__ void __launch_bounds__(256)
+conv_first_wide_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ scale,
+                       const float* __restrict__ shift, char* __restrict__ y, int H, int W, int y_ld, int act) {
+    constexpr int TH = 16, TW = 64, PH = TH + 2, PW = TW + 3, Cout = 16 * NQ;
+    extern __shared__ __attribute__((aligned(16))) float fl[];
+    float* patch = fl;                          // [3][PH][PW]
+    float* wl = fl + 3 * PH * PW;               // [Cout][32]
+    const int b = blockIdx.z, oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 3 * PH * (TW + 2); i += 256) {
+        const int c = i / (PH * (TW + 2)), rem = i - c * PH * (TW + 2);
+        const int iy = rem / (TW + 2), ix = rem - iy * (TW + 2);
+        const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+        patch[(c * PH + iy) * PW + ix] =
+            (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(((size_t)b * 3 + c) * H + gy) * W + gx] : 0.0f;
+    }
+    for (int i = tid; i < Cout * 32; i += 256) {
+        const int co = i >> 5, k = i & 31;
+        wl[i] = k < 27 ? w[co * 27 + k] : 0.0f;
+    }
+    __syncthreads();
+    const int j = lane & 15, kg = lane >> 4;
+    int off[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int k = 8 * kg + e;
+        if (k > 26) k = 26;
+        const int c = k % 3, t = k / 3;
+        off[e] = (c * PH + t / 3) * PW + t % 3;
+    }
+    bf16x8_t wb[NQ];
+    float sc[NQ][4], sh[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int row = 4 * NQ * (j >> 2) + 4 * q + (j & 3);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wb[q][e] = (short)f32_to_bf16(wl[row * 32 + 8 * kg + e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = 4 * NQ * kg + 4 * q + e;
+            sc[q][e] = scale ? scale[co] : 1.0f;
+            sh[q][e] = scale ? shift[co] : 0.0f;
+        }
+    }
+    const int tx = wave * 16 + j;
+    const float* src[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) src[e] = patch + tx + off[e];
+#pragma unroll 2
+    for (int ty = 0; ty < TH; ++ty) {
+        u32x4 xw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xw[e] = f32x2_to_bf16x2(src[2 * e][ty * PW], src[2 * e + 1][ty * PW]);
+        f32x4_t d[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+            d[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[q], __builtin_bit_cast(bf16x8_t, xw), zero, 0, 0, 0);
+        }
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        if (oy >= H || ox >= W) continue;
+        uint32_t pk[2 * NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = scale ? d[q][e] * sc[q][e] + sh[q][e] : d[q][e];
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = silu<ODAMD_DTYPE_BF16>(o[e]);
+            }
+            pk[2 * q] = f32x2_to_bf16x2(o[0], o[1]);
+            pk[2 * q + 1] = f32x2_to_bf16x2(o[2], o[3]);
+        }
+        char* dst = y + ((((size_t)b * H + oy) * W + ox) * y_ld + 4 * NQ * kg) * 2;
+#pragma unroll
+        for (int v = 0; v < NQ / 2; ++v) *(u32x4*)(dst + 16 * v) = u32x4{pk[4 * v], pk[4 * v + 1], pk[4 * v + 2], pk[4 * v + 3]};
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // first + second layer in one launch (bf16): cbs0 (3 -> 16, 3x3 stride 1) feeding cbs1 (16 -> 32,
 // 3x3 stride 2).  The 16-channel full-resolution activation between them is the largest tensor of
@@ -1568,8 +1655,12 @@ DmaConfig dma_config(const ConvP& p, int ks, int stride, int dtype) {
         if (g_lab_force.pg) return g_lab_force.ks == ks && g_lab_force.st == 2 ? g_lab_force : none;
         if (g_lab_no_dma_s2) return none;
 #endif
-        // mp.cbs3 (model/layer.py:143): 3x3 stride 2 with 64 .. 256 channels on <= 160 x 160 inputs
-        if (ks != 3 || p.Cin < 64 || p.Cin % 16 || p.Cout < 64 || p.H * p.W > 160 * 160) return none;
+        // mp.cbs3 (model/layer.py:143): 3x3 stride 2 with 64 .. 256 channels on <= 160 x 160 inputs; with 128 output
+        // channels and more also the stem layers of the wider presets on their 320 x 320 / 640 x 640 inputs
+        // (measured at batch 64: 128 -> 256 at 320 x 320 1.87 -> 1.54 ms, 64 -> 128 at 640 x 640 2.15 -> 2.01 ms)
+        if (ks != 3 || p.Cin < 64 || p.Cin % 16 || p.Cout < 64) return none;
+        if (p.H * p.W > 160 * 160 && p.Cout < 128) return none;
+        if ((long long)p.B * ((p.Ho * p.Wo + 63) / 64) * ((p.Cout + 63) / 64) >= (1 << 21)) return none;   // block index range of the kernel
         if (!choose_tile_s2(p.Ho, p.Wo, 4, dma_max_in_pix(3, 4, 2)).ok) return none;
         // measured at batch 64 (tools/micro/conv_lab.hip): 128 output channels per workgroup from 128 channels up
         if (p.Cout >= 128) return {3, 4, 4, 2, 2, 32, 2, 2};
@@ -1583,7 +1674,10 @@ DmaConfig dma_config(const ConvP& p, int ks, int stride, int dtype) {
     // measured against conv_igemm_kernel / conv1x1_stream_kernel at batch 64 (tools/micro/conv_lab.hip): the DMA
     // kernel wins where K = taps * cin is deep and the map is small (weights dominate the staged bytes)
     if (ks == 3) {
-        if (p.Cin < 64 || p.Cout < 64 || p.H * p.W > 80 * 80) return none;
+        // larger maps only from 128 input channels (K = 1152) up: 128 -> 128 at 160 x 160 0.74 -> 0.52 ms, at
+        // 320 x 320 2.78 -> 2.07 ms (the ELAN chains and the stem of the widest preset)
+        if (p.Cin < 64 || p.Cout < 64 || (p.H * p.W > 80 * 80 && p.Cin < 128)) return none;
+        if ((long long)p.B * ((p.H * p.W + 63) / 64) * ((p.Cout + 63) / 64) >= (1 << 21)) return none;
         return {3, 8, 2, 4, 1, 32, 2, 1};
     }
     if (ks == 1) {
@@ -2075,6 +2169,10 @@ int odamd_conv_first_forward(const float* image, const float* w, const float* sc
     if (dtype == ODAMD_DTYPE_F32)   // float32 keeps the scalar fma chain (bit-stable against the float32 parity fixtures)
         conv_first_valu_kernel<ODAMD_DTYPE_F32><<<dim3((w_in + 15) / 16, (h + 15) / 16, batch), 256, 0, (hipStream_t)stream>>>(
             image, w, scale, shift, (char*)y, h, w_in, cout, y_ld, act);
+    else if (cout == 64)
+        conv_first_wide_kernel<4><<<grid, 256, lds, (hipStream_t)stream>>>(image, w, scale, shift, (char*)y, h, w_in, y_ld, act);
+    else if (cout == 32)
+        conv_first_wide_kernel<2><<<grid, 256, lds, (hipStream_t)stream>>>(image, w, scale, shift, (char*)y, h, w_in, y_ld, act);
     else
         conv_first_kernel<ODAMD_DTYPE_BF16><<<grid, 256, lds, (hipStream_t)stream>>>(image, w, scale, shift, (char*)y, h, w_in, cout, y_ld, act);
     return (int)hipGetLastError();

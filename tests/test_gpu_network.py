@@ -63,6 +63,11 @@ BLOCK_CASES = [
     ('cbs', dict(in_=256, out_=256, kernel_size=3, stride=2), (1, 256, 40, 40)),
     ('cbs', dict(in_=64, out_=96, kernel_size=3, stride=2), (2, 64, 37, 53)),
     ('cbs', dict(in_=80, out_=200, kernel_size=3, stride=2), (1, 80, 26, 30)),
+    # the same kernels on maps beyond 80 x 80 (stride 1, from 128 input channels) / beyond 160 x 160 inputs (stride 2, from
+    # 128 output channels): the ELAN chains and the stem of the widest preset
+    ('cbs', dict(in_=128, out_=128, kernel_size=3, stride=1), (1, 128, 100, 100)),
+    ('cbs', dict(in_=160, out_=64, kernel_size=3, stride=1), (1, 160, 90, 97)),
+    ('cbs', dict(in_=64, out_=128, kernel_size=3, stride=2), (1, 64, 200, 180)),
     # 256 / 512 / 1024 input channels, output channels in multiples of 128, pixel count a multiple of 64: the persistent
     # 1x1 kernel with register-resident weights (1..3 channel blocks, one and two channel groups per wave, fewer tiles
     # than workgroups, odd tile counts, several rounds per workgroup)
@@ -222,7 +227,7 @@ def test_network_640_bf16_vs_f32_oracle(od):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
-@pytest.mark.parametrize('cout,h,w', [(16, 64, 64), (24, 37, 70), (40, 16, 130)])
+@pytest.mark.parametrize('cout,h,w', [(16, 64, 64), (24, 37, 70), (40, 16, 130), (32, 50, 77), (64, 33, 130)])
 def test_first_layer_entry_point(cout, h, w, dtype):
     """odamd_conv_first_forward alone (weights [cout][ky][kx][3]) against torch conv2d on random data."""
     from objectdetection_amd._lib import lib, check

@@ -7,7 +7,8 @@
     ODAMD_DMA_CASE(3, 8, 2, 4, 1, 32, 3) ODAMD_DMA_CASE(3, 8, 2, 4, 1, 64, 2) ODAMD_DMA_CASE(3, 4, 2, 2, 2, 32, 3) \
     ODAMD_DMA_CASE(3, 4, 2, 4, 1, 32, 3) ODAMD_DMA_CASE(3, 4, 4, 2, 2, 32, 2) ODAMD_DMA_CASE(3, 8, 4, 4, 2, 32, 2) \
     ODAMD_DMA_CASE(3, 8, 4, 4, 2, 32, 3) ODAMD_DMA_CASE(1, 4, 4, 2, 2, 128, 2) ODAMD_DMA_CASE(1, 8, 4, 2, 2, 128, 2) ODAMD_DMA_CASE(1, 4, 4, 2, 2, 64, 2) \
-    ODAMD_DMA_CASE(1, 8, 4, 4, 2, 64, 3) ODAMD_DMA_CASE(1, 8, 8, 4, 2, 64, 2) ODAMD_DMA_CASE(1, 8, 4, 4, 2, 128, 2)
+    ODAMD_DMA_CASE(1, 8, 4, 4, 2, 64, 3) ODAMD_DMA_CASE(1, 8, 8, 4, 2, 64, 2) ODAMD_DMA_CASE(1, 8, 4, 4, 2, 128, 2) \
+    ODAMD_DMA_CASE(3, 8, 4, 2, 2, 32, 2) ODAMD_DMA_CASE(3, 8, 2, 4, 2, 32, 2)
 #define LAB_S3_VARIANTS \
     ODAMD_S3_CASE(2, 1, 1, 4, 256, 3) ODAMD_S3_CASE(2, 1, 1, 4, 256, 4) ODAMD_S3_CASE(2, 1, 1, 8, 384, 3) \
     ODAMD_S3_CASE(2, 2, 2, 4, 640, 2) ODAMD_S3_CASE(4, 2, 1, 4, 256, 2) ODAMD_S3_CASE(4, 2, 1, 4, 192, 3) \
@@ -51,6 +52,14 @@ int main(int argc, char** argv) {
         {"3x3s2 64->64 @160", 160, 64, 64, 3, 2, 0},   {"3x3s2 128->128 @80", 80, 128, 128, 3, 2, 0},
         {"3x3s2 64->64 @80", 80, 64, 64, 3, 2, 0},
         {"3x3 64->32 @80", 80, 64, 32, 3, 1, 0},
+        // preset l (base width 64)
+        {"3x3 128->128 @160", 160, 128, 128, 3, 1, 0}, {"3x3 128->128 @320", 320, 128, 128, 3, 1, 0},          // 30, 31
+        {"3x3 256->256 @80", 80, 256, 256, 3, 1, 0},   {"3x3 512->512 @40", 40, 512, 512, 3, 1, 0},            // 32, 33
+        {"3x3s2 64->128 @640", 640, 64, 128, 3, 2, 0}, {"3x3s2 128->256 @320", 320, 128, 256, 3, 2, 0},        // 34, 35
+        {"3x3s2 256->256 @160", 160, 256, 256, 3, 2, 0}, {"1x1 2048->2048 @40", 40, 2048, 2048, 1, 1, 0},      // 36, 37
+        {"1x1 1024->1024 @80", 80, 1024, 1024, 1, 1, 0}, {"1x1 4096->1024 @20", 20, 4096, 1024, 1, 1, 0},      // 38, 39
+        {"1x1 2048->1024 @20", 20, 2048, 1024, 1, 1, 0}, {"1x1 512->512 @160", 160, 512, 512, 1, 1, 0},        // 40, 41
+        {"3x3 1024->1024 @20", 20, 1024, 1024, 3, 1, 0},                                                        // 42
     };
     const int only = argc > 1 ? atoi(argv[1]) : -1;
     S3Config s3_env = {};       // LAB_S3="ksteps,cg,st,pg,npad,nbuf": the persistent 3x3 kernel instantiation to force
@@ -133,7 +142,7 @@ int main(int argc, char** argv) {
             {-1, 4, 256, 3, 0, 0, 0}, {-1, 4, 256, 4, 0, 0, 0}, {-1, 8, 384, 3, 0, 0, 0}, {-2, 4, 640, 2, 0, 0, 0},   // conv_s3 variants: pg, npad, nbuf
             {3, 8, 2, 4, 1, 32, 2, 2}, {3, 4, 2, 4, 1, 32, 3, 2}, {3, 4, 2, 4, 1, 64, 2, 2}, {3, 4, 4, 2, 2, 32, 2, 2}, {3, 4, 2, 2, 2, 32, 2, 2},
             {3, 8, 2, 4, 1, 64, 2}, {3, 8, 2, 4, 1, 32, 3}, {3, 8, 2, 4, 1, 32, 2}, {3, 4, 2, 2, 2, 32, 3}, {3, 4, 2, 4, 1, 32, 3},
-            {3, 4, 4, 2, 2, 32, 2}, {3, 8, 4, 4, 2, 32, 2}, {3, 8, 4, 4, 2, 32, 3}, {1, 8, 4, 2, 2, 128, 2}, {1, 4, 4, 2, 2, 128, 2},
+            {3, 4, 4, 2, 2, 32, 2}, {3, 8, 4, 4, 2, 32, 2}, {3, 8, 4, 4, 2, 32, 3}, {3, 8, 4, 2, 2, 32, 2}, {3, 8, 2, 4, 2, 32, 2}, {1, 8, 4, 2, 2, 128, 2}, {1, 4, 4, 2, 2, 128, 2},
             {1, 4, 4, 2, 2, 64, 3}, {1, 4, 4, 2, 2, 64, 2}, {1, 8, 4, 4, 2, 64, 3}, {1, 8, 8, 4, 2, 64, 2}, {1, 8, 4, 4, 2, 128, 2}};
         double best = us;
         for (const DmaConfig& v : variants) {
