@@ -21,6 +21,7 @@
 #include "odamd.h"
 
 #include <mutex>
+#include <utility>
 
 // Scratch of odamd_nms_rows_static, the entry point that allocates nothing.  Every GPU the library
 // runs on holds its own copy of this array, at its own address, until the process ends.  In host
@@ -794,6 +795,67 @@ iou_mask_kernel(const float4* __restrict__ sbox, const float4* __restrict__ colp
 //   a column is dropped when that bound, taken with the widest and the tallest row of the wave, stays
 //   below fl(min_row(k_lo * area_row) + k_lo * area_col) <= the pair's own threshold.
 // ------------------------------------------------------------------------------------------
+// Between two chunks of the greedy pass: rows [0, r1) of the sorted candidate list are decided (kept ones are in the
+// output already), and every later candidate whose bit in `removed` is set will never be looked at again.  The
+// survivors move to the front of the other copy of the list (order preserved, so the greedy result is the same), the
+// count shrinks and `removed` starts again at zero: the next chunk's mask has neither dead rows (a wave of 64 rows with
+// a few live lanes costs what a full one costs) nor dead columns.  One workgroup per image.
+constexpr int COMPACT_THREADS = 1024;
+constexpr int COMPACT_MAX_WORDS = 4096;       // n_pad <= 2^18
+
+__global__ void __launch_bounds__(COMPACT_THREADS)
+compact_live_kernel(const float4* __restrict__ sbox_in, const int* __restrict__ srow_in, float4* __restrict__ sbox_out,
+                    int* __restrict__ srow_out, int* __restrict__ count, u64* __restrict__ removed, int n_pad, int r1) {
+    __shared__ u64 live[COMPACT_MAX_WORDS];
+    __shared__ int base[COMPACT_MAX_WORDS];
+    __shared__ int part[COMPACT_THREADS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(count[b], n_pad);
+    const int words = n_pad >> 6, nw = (n + 63) >> 6, w1 = r1 >> 6;
+    u64* rem = removed + (size_t)b * words;
+    constexpr int PER = COMPACT_MAX_WORDS / COMPACT_THREADS;
+    int local = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int w = tid * PER + k;
+        u64 bits = 0;
+        if (w >= w1 && w < nw) {
+            bits = ~rem[w];
+            if (n - w * 64 < 64) bits &= (1ull << (n - w * 64)) - 1ull;
+        }
+        if (w < COMPACT_MAX_WORDS) { live[w] = bits; base[w] = local; }
+        local += __popcll(bits);
+    }
+    part[tid] = local;
+    __syncthreads();
+    for (int d = 1; d < COMPACT_THREADS; d <<= 1) {
+        const int t = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
+    }
+    const int total = part[COMPACT_THREADS - 1];
+    const int mine = part[tid] - local;                // exclusive prefix of this thread's words
+#pragma unroll
+    for (int k = 0; k < PER; ++k) base[tid * PER + k] += mine;
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    const float4* si = sbox_in + (size_t)b * n_pad;
+    const int* ri = srow_in + (size_t)b * n_pad;
+    float4* so = sbox_out + (size_t)b * n_pad;
+    int* ro = srow_out + (size_t)b * n_pad;
+    for (int w = w1 + wave; w < nw; w += COMPACT_THREADS / 64) {
+        const u64 bits = live[w];
+        if ((bits >> lane) & 1ull) {
+            const int pos = base[w] + __popcll(bits & ((1ull << lane) - 1ull));
+            so[pos] = si[w * 64 + lane];
+            ro[pos] = ri[w * 64 + lane];
+        }
+    }
+    for (int w = tid; w < nw; w += COMPACT_THREADS) rem[w] = 0ull;
+    if (tid == 0) count[b] = total;
+}
+
 constexpr int AREA_BLOCK = 1024;
 
 __global__ void __launch_bounds__(256)
@@ -1112,19 +1174,25 @@ nms_scan_kernel(const u64* __restrict__ mask, size_t mask_stride_img, const int*
                 if (2 * pair > t && acc0) atomicOr((unsigned long long*)&removed[2 * pair], (unsigned long long)acc0);
                 if (2 * pair + 1 < nwords && acc1) atomicOr((unsigned long long*)&removed[2 * pair + 1], (unsigned long long)acc1);
             }
-            // further column words (more than 16384 candidates): loaded here, four batches of 16
+            // further column words (more than 16384 candidates): loaded here, and only for the rows that were kept (the
+            // outcome is known and wave-uniform by now; with dense candidates most rows of a tile are suppressed), in
+            // batches of eight loads
             for (int w = w0 + 2 * SCAN_PAIRS; w < nwords; w += SCAN_GROUP) {
                 if (w <= t) continue;
-                u64 acc = 0;
+                u64 acc = 0, todo = kept;
 #pragma unroll 1
-                for (int q0 = 0; q0 < 64; q0 += 16) {
-                    u64 x[16];
+                while (todo) {
+                    u64 x[8];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) x[u] = mt[(size_t)(q0 + u) * words + w];
+                    for (int u = 0; u < 8; ++u) {
+                        const int q = todo ? __builtin_ctzll(todo) : -1;      // uniform
+                        todo = todo ? (todo & (todo - 1ull)) : 0ull;
+                        x[u] = q >= 0 ? mt[(size_t)q * words + w] : 0ull;
+                    }
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) acc |= ((kept >> (q0 + u)) & 1ull) ? x[u] : 0ull;
+                    for (int u = 0; u < 8; ++u) acc |= x[u];
                 }
-                removed[w] |= acc;
+                if (acc) removed[w] |= acc;
             }
             mine += SCAN_GROUPS;
             fetch_diag(mine);                          // two loads; the rows follow at the top of the next iteration
@@ -1392,6 +1460,8 @@ struct Workspace {
     u64* keys;
     float4* rowbox;
     float4* sbox;
+    float4* sbox2;   // second copies of the sorted list: compact_live_kernel moves the survivors from one to the other
+    int* srow2;
     float4* colpk;   // column operands of the mask kernel (pack_cols_kernel)
     float* colk;
     int* srow;
@@ -1417,12 +1487,18 @@ Workspace carve(char* base, int batch, int rows, int n_pad) {
     w.colpk = (float4*)take((size_t)batch * n_pad * 16);
     w.colk = (float*)take((size_t)batch * n_pad * 4);
     w.srow = (int*)take((size_t)batch * n_pad * 4);
+    w.sbox2 = (float4*)take((size_t)batch * n_pad * 16);
+    w.srow2 = (int*)take((size_t)batch * n_pad * 4);
     w.perm = (int*)take((size_t)batch * n_pad * 4);
     w.removed = (u64*)take((size_t)batch * (n_pad / 64) * 8);
     w.count = (int*)take((size_t)batch * 4);
     w.count_pad = (int*)take((size_t)batch * COUNT_STRIDE * 4);
-    // mask chunk: at most 16 MiB per image, whole 64-row tiles
-    long long chunk = (16ll << 20) * 8 / n_pad;
+    // mask chunk: whole 64-row tiles, at most 64 MiB per image and 1 GiB per batch (16 MiB per image from 64 images up):
+    // fewer, larger chunks for small batches of dense images, whose chunk launches are otherwise latency bound
+    long long per_image = (1ll << 30) / batch;
+    if (per_image > (64ll << 20)) per_image = 64ll << 20;
+    if (per_image < (16ll << 20)) per_image = 16ll << 20;
+    long long chunk = per_image * 8 / n_pad;
     chunk = (chunk / 64) * 64;
     if (chunk < 64) chunk = 64;
     if (chunk > n_pad) chunk = n_pad;
@@ -1445,33 +1521,46 @@ int sort_keys(u64* keys, const int* count, int batch, int n_pad, hipStream_t st)
     return (int)hipGetLastError();
 }
 
-int run_nms(const Workspace& w, const int* count, int batch, int rows, int n_pad, float iou_thr, int corner_rule, int* out_idx,
+int run_nms(const Workspace& w, int* count, int batch, int rows, int n_pad, float iou_thr, int corner_rule, int* out_idx,
             int* out_count, int max_keep, hipStream_t st) {
     const int words = n_pad / 64;
-    pack_cols_kernel<<<dim3((n_pad + 255) / 256, batch), 256, 0, st>>>(w.sbox, count, n_pad, iou_thr, w.colpk, w.colk);
     // rows grouped by size inside 1024-row blocks need chunks made of whole blocks
     const bool windowed = n_pad % AREA_BLOCK == 0 && w.chunk_rows % AREA_BLOCK == 0;
-    if (windowed) area_order_kernel<<<dim3(n_pad / AREA_BLOCK, batch), 256, 0, st>>>(w.sbox, count, n_pad, w.perm);
-    // an image has at most `rows` candidates: chunks beyond them would be empty launches
+    float4* sbox = w.sbox;
+    float4* sbox_alt = w.sbox2;
+    int* srow = w.srow;
+    int* srow_alt = w.srow2;
+    // an image has at most `rows` candidates: chunks beyond them would be empty launches.  Every pass handles rows
+    // [0, chunk) of the CURRENT list: after a pass the decided rows and the suppressed candidates are dropped
+    // (compact_live_kernel: `count` shrinks, `removed` restarts at zero), so with nothing suppressed at all pass k sees
+    // the original rows [k * chunk, (k + 1) * chunk) - the host's loop bound is that worst case, passes over an empty list
+    // return at once.
     const int r_end = rows < n_pad ? rows : n_pad;
+    const int r1 = w.chunk_rows < n_pad ? w.chunk_rows : n_pad;
     for (int r0 = 0; r0 < r_end; r0 += w.chunk_rows) {
-        const int r1 = r0 + w.chunk_rows < n_pad ? r0 + w.chunk_rows : n_pad;
-        const int gx = (words + MASK_WAVES - 1) / MASK_WAVES, gy = (r1 - r0) / 64;
+        pack_cols_kernel<<<dim3((n_pad + 255) / 256, batch), 256, 0, st>>>(sbox, count, n_pad, iou_thr, w.colpk, w.colk);
+        if (windowed) area_order_kernel<<<dim3(n_pad / AREA_BLOCK, batch), 256, 0, st>>>(sbox, count, n_pad, w.perm);
+        const int gx = (words + MASK_WAVES - 1) / MASK_WAVES, gy = r1 / 64;
         // the windowed kernel does its per-row-group set-up once per workgroup row: more rows, fewer column strides
         // (about 256 workgroups per image either way)
         const int ly = windowed ? 64 : 32;
         const int lx = windowed ? (gy >= 64 ? 4 : 256 / gy) : 8;
         dim3 grid(gx < lx ? gx : lx, gy < ly ? gy : ly, batch);
         if (windowed)
-            iou_mask_win_kernel<<<grid, 64 * MASK_WAVES, 0, st>>>(w.sbox, w.colpk, w.colk, w.perm, count, w.removed, n_pad,
-                                                                   r0, r1, iou_thr, corner_rule, w.mask,
+            iou_mask_win_kernel<<<grid, 64 * MASK_WAVES, 0, st>>>(sbox, w.colpk, w.colk, w.perm, count, w.removed, n_pad,
+                                                                   0, r1, iou_thr, corner_rule, w.mask,
                                                                    w.mask_stride_img);
         else
-            iou_mask_kernel<true><<<grid, 64 * MASK_WAVES, 0, st>>>(w.sbox, w.colpk, w.colk, count, w.removed, n_pad, r0,
+            iou_mask_kernel<true><<<grid, 64 * MASK_WAVES, 0, st>>>(sbox, w.colpk, w.colk, count, w.removed, n_pad, 0,
                                                                      r1, iou_thr, corner_rule, w.mask, w.mask_stride_img);
-        nms_scan_kernel<<<batch, SCAN_THREADS, (size_t)words * 8, st>>>(w.mask, w.mask_stride_img, count, w.srow,
-                                                                        w.removed, n_pad, r0, r1, out_idx, out_count,
+        nms_scan_kernel<<<batch, SCAN_THREADS, (size_t)words * 8, st>>>(w.mask, w.mask_stride_img, count, srow,
+                                                                        w.removed, n_pad, 0, r1, out_idx, out_count,
                                                                         max_keep);
+        if (r0 + w.chunk_rows < r_end) {
+            compact_live_kernel<<<batch, COMPACT_THREADS, 0, st>>>(sbox, srow, sbox_alt, srow_alt, count, w.removed, n_pad, r1);
+            std::swap(sbox, sbox_alt);
+            std::swap(srow, srow_alt);
+        }
     }
     return (int)hipGetLastError();
 }
@@ -1520,9 +1609,9 @@ int postprocess_impl(const float* pred, const DecodeGeom& g, int batch, int rows
     if ((rc = sort_keys(w.keys, w.count, batch, n_pad, st))) return rc;
     gather_sorted_kernel<<<dim3((n_pad + 255) / 256, batch), 256, 0, st>>>(w.keys, w.rowbox, w.count, rows, n_pad,
                                                                            SRC >= 3, w.sbox, w.srow);
-    if ((rc = run_nms(w, w.count, batch, rows, n_pad, iou_thr, SRC >= 3, out_idx, out_count, max_keep, st))) return rc;
-    if (cand_count)
+    if (cand_count)     // before the greedy pass: it shrinks the list (and its count) as it goes
         if ((rc = (int)hipMemcpyAsync(cand_count, w.count, (size_t)batch * 4, hipMemcpyDeviceToDevice, st))) return rc;
+    if ((rc = run_nms(w, w.count, batch, rows, n_pad, iou_thr, SRC >= 3, out_idx, out_count, max_keep, st))) return rc;
     if (out_rows) {
         const int gx = (max_keep + 4 * EMIT_ROWS - 1) / (4 * EMIT_ROWS);
         bool lean = SRC == 1;
