@@ -432,67 +432,113 @@ maxpool_s1_bwd_bf16_kernel(const char* __restrict__ x, int x_ld, const char* __r
 // The three stride-1 max pools of an SPP block (k = 5, 9, 13 on the same input, model/layer.py:215-217) in one launch.
 // The first maximum of a window in row-major order is the leftmost maximum of the first row that holds the maximum, so
 // the search separates: pass 1 finds, per pixel and width, the leftmost maximum of its row segment (one left-to-right
-// walk over 13 elements serves the three nested widths) and keeps (value, column) packed in LDS — the values are bf16,
-// 16 bits; pass 2 walks the rows of each window top-down over those records.  54 comparisons per element instead of
-// 25 + 81 + 169; the three gradients are added to a float32 plane in LDS and dx is read and written once.
+// walk over 13 elements serves the three nested widths); pass 2 walks the rows of each window top-down over those
+// records.  54 comparisons per element instead of 25 + 81 + 169.
+// No atomics at all (float32 and bf16): the scatter "add the window's gradient at its
+// arg-max" becomes a gather.  Pass 1 and 2 as above, but pass 2 only RECORDS every window's arg-max pixel (and its
+// gradient) in LDS; in pass 3 every input element walks the windows that contain it, in a fixed order (k = 5, 9, 13,
+// rows, columns), and adds the gradients of those whose arg-max it is.  Float addition in a fixed order: the result is
+// bitwise repeatable, which LDS / global float atomics are not as soon as three windows meet in one element.
+// One workgroup per (image, 16-byte channel vector); per element of the plane: value / sum (float), three gradients
+// (storage type), three row-maximum columns (bytes: W <= 255) and three arg-max pixels (16 bits: H * W <= 65535).
+template <int DT> struct SppStore;
+template <> struct SppStore<ODAMD_DTYPE_F32> {
+    typedef float T;
+    static __device__ __forceinline__ float get(float v) { return v; }
+};
+template <> struct SppStore<ODAMD_DTYPE_BF16> {
+    typedef uint16_t T;
+    static __device__ __forceinline__ float get(uint16_t v) { return bf16_to_f32(v); }
+};
+template <int DT>
+__host__ __device__ constexpr size_t spp_gather_bytes_per_pixel() {
+    return (size_t)Vec<DT>::N * (sizeof(float) + 3 * sizeof(typename SppStore<DT>::T) + 3 + 3 * sizeof(uint16_t));
+}
+
+template <int DT>
 __global__ void __launch_bounds__(256)
-spp_bwd_bf16_kernel(const char* __restrict__ x, int x_ld, const char* __restrict__ dy5, const char* __restrict__ dy9,
-                    const char* __restrict__ dy13, int dy_ld, char* __restrict__ dx, int dx_ld, int H, int W) {
+spp_bwd_gather_kernel(const char* __restrict__ x, int x_ld, const char* __restrict__ dy5, const char* __restrict__ dy9,
+                      const char* __restrict__ dy13, int dy_ld, char* __restrict__ dx, int dx_ld, int H, int W) {
+    constexpr int N = Vec<DT>::N, ES = Vec<DT>::ES;
+    typedef typename SppStore<DT>::T S;
     extern __shared__ __attribute__((aligned(16))) float pl[];
-    const int hw = H * W, v = blockIdx.x, b = blockIdx.y;
-    float* grad = pl;                                        // [hw][8]
-    uint16_t* val = (uint16_t*)(pl + (size_t)hw * 8);        // [hw][8] bf16 bits
-    uint32_t* rec = (uint32_t*)(val + (size_t)hw * 8);       // [3 widths][hw][8]: value bits << 16 | column
+    const int hw = H * W, v = blockIdx.x, b = blockIdx.y, ne = hw * N;
+    float* val = pl;                                   // [hw][N]; the gradient sums from pass 3 on
+    S* dyv = (S*)(val + ne);                           // [3][hw][N]
+    uint16_t* argw = (uint16_t*)(dyv + 3 * ne);        // [3][hw][N]
+    uint8_t* rcol = (uint8_t*)(argw + 3 * ne);         // [3][hw][N]
+    const char* dys[3] = {dy5, dy9, dy13};
     for (int p = threadIdx.x; p < hw; p += 256) {
-        const uint4 t = *(const uint4*)(x + (((size_t)b * hw + p) * x_ld) * 2 + v * 16);
-        *(uint4*)(val + p * 8) = t;
+        float t[N];
+        Vec<DT>::load(x + (((size_t)b * hw + p) * x_ld) * ES + v * 16, t);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) grad[p * 8 + e] = 0.0f;
+        for (int e = 0; e < N; ++e) val[p * N + e] = t[e];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const char* g = dys[k] + (((size_t)b * hw + p) * dy_ld) * ES + v * 16;
+#pragma unroll
+            for (int e = 0; e < N; ++e) dyv[k * ne + p * N + e] = ((const S*)g)[e];
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < hw * 8; i += 256) {       // pass 1: leftmost row maxima of widths 5, 9, 13
-        const int e = i & 7, p = i >> 3;
+    for (int i = threadIdx.x; i < ne; i += 256) {      // pass 1: leftmost row maxima of widths 5, 9, 13
+        const int e = i % N, p = i / N;
         const int oy = p / W, ox = p - oy * W;
         float m5 = -INFINITY, m9 = -INFINITY, m13 = -INFINITY;
-        uint32_t r5 = 0, r9 = 0, r13 = 0;
+        int c5 = ox, c9 = ox, c13 = ox;
         for (int gx = max(ox - 6, 0); gx <= min(ox + 6, W - 1); ++gx) {
-            const uint32_t bits = val[(oy * W + gx) * 8 + e];
-            const float t = __uint_as_float(bits << 16);
-            const uint32_t packed = (bits << 16) | (uint32_t)gx;
+            const float t = val[(oy * W + gx) * N + e];
             const int d = abs(gx - ox);
-            if (t > m13) { m13 = t; r13 = packed; }
-            if (d <= 4 && t > m9) { m9 = t; r9 = packed; }
-            if (d <= 2 && t > m5) { m5 = t; r5 = packed; }
+            if (t > m13) { m13 = t; c13 = gx; }
+            if (d <= 4 && t > m9) { m9 = t; c9 = gx; }
+            if (d <= 2 && t > m5) { m5 = t; c5 = gx; }
         }
-        rec[i] = r5; rec[hw * 8 + i] = r9; rec[2 * hw * 8 + i] = r13;
+        rcol[i] = (uint8_t)c5; rcol[ne + i] = (uint8_t)c9; rcol[2 * ne + i] = (uint8_t)c13;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < hw * 8; i += 256) {       // pass 2: first row holding the window maximum
-        const int e = i & 7, p = i >> 3;
+    for (int i = threadIdx.x; i < ne; i += 256) {      // pass 2: first row holding the window maximum
+        const int e = i % N, p = i / N;
         const int oy = p / W, ox = p - oy * W;
-        const size_t go = (((size_t)b * hw + p) * dy_ld) * 2 + v * 16 + e * 2;
-        const char* dys[3] = {dy5, dy9, dy13};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int rad = 2 + 2 * k;
             float m = -INFINITY;
-            int arg = 0;
+            int arg = p;
             for (int gy = max(oy - rad, 0); gy <= min(oy + rad, H - 1); ++gy) {
-                const uint32_t r = rec[(k * hw + gy * W + ox) * 8 + e];
-                const float t = __uint_as_float(r & 0xFFFF0000u);
-                if (t > m) { m = t; arg = gy * W + (int)(r & 0xFFFFu); }
+                const int c = rcol[k * ne + (gy * W + ox) * N + e];
+                const float t = val[(gy * W + c) * N + e];
+                if (t > m) { m = t; arg = gy * W + c; }
             }
-            atomicAdd(&grad[arg * 8 + e], bf16_to_f32(*(const uint16_t*)(dys[k] + go)));
+            argw[k * ne + i] = (uint16_t)arg;
         }
     }
     __syncthreads();
-    for (int p = threadIdx.x; p < hw; p += 256) {
-        float t[8];
-        char* d = dx + (((size_t)b * hw + p) * dx_ld) * 2 + v * 16;
-        Vec<ODAMD_DTYPE_BF16>::load(d, t);
+    for (int i = threadIdx.x; i < ne; i += 256) {      // pass 3: gather, fixed order
+        const int e = i % N, p = i / N;
+        const int py = p / W, px = p - py * W;
+        float sum = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) t[e] += grad[p * 8 + e];
-        Vec<ODAMD_DTYPE_BF16>::store(d, t);
+        for (int k = 0; k < 3; ++k) {
+            const int rad = 2 + 2 * k;
+            const uint16_t* aw = argw + k * ne + e;
+            const S* dv = dyv + k * ne + e;
+            for (int wy = max(py - rad, 0); wy <= min(py + rad, H - 1); ++wy)
+                for (int wx = max(px - rad, 0); wx <= min(px + rad, W - 1); ++wx) {
+                    const int q = (wy * W + wx) * N;
+                    if (aw[q] == (uint16_t)p) sum += SppStore<DT>::get(dv[q]);
+                }
+        }
+        // every element writes its own slot; nobody reads `val` as values any more (pass 2 is behind the barrier)
+        val[i] = sum;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < hw; p += 256) {
+        float t[N];
+        char* d = dx + (((size_t)b * hw + p) * dx_ld) * ES + v * 16;
+        Vec<DT>::load(d, t);
+#pragma unroll
+        for (int e = 0; e < N; ++e) t[e] += val[p * N + e];
+        Vec<DT>::store(d, t);
     }
 }
 
@@ -1567,24 +1613,37 @@ int odamd_spp_backward(const void* x, int x_ld, const void* dy5, const void* dy9
                        int dx_ld, int batch, int h, int w, int c, int dtype, void* stream) {
     if (!x || !dy5 || !dy9 || !dy13 || !dx || batch < 1 || h < 1 || w < 1 || c < 1) return ODAMD_E_ARG;
     if (dtype != ODAMD_DTYPE_F32 && dtype != ODAMD_DTYPE_BF16) return ODAMD_E_ARG;
-    // LDS of the one-launch form: float32 gradient plane, bf16 values, three planes of packed row records
-    const size_t spp_lds = (size_t)h * w * 8 * (sizeof(float) + sizeof(uint16_t) + 3 * sizeof(uint32_t));
-    if (dtype == ODAMD_DTYPE_F32 || spp_lds > 64 * 1024) {
-        // float32, or planes beyond the LDS form: the three pools one after the other
-        const void* dys[3] = {dy5, dy9, dy13};
-        const int ks[3] = {5, 9, 13};
-        for (int i = 0; i < 3; ++i) {
-            const int rc = odamd_maxpool_s1_backward(x, x_ld, dys[i], dy_ld, dx, dx_ld, batch, h, w, c, ks[i], dtype, stream);
-            if (rc) return rc;
+    const int per = dtype == ODAMD_DTYPE_F32 ? 4 : 8;
+    const bool aligned = !((c % per) || (x_ld % per) || (dy_ld % per) || (dx_ld % per) || ((uintptr_t)x & 15) || ((uintptr_t)dy5 & 15) ||
+                           ((uintptr_t)dy9 & 15) || ((uintptr_t)dy13 & 15) || ((uintptr_t)dx & 15));
+    // one launch, no atomics, bitwise repeatable: planes whose per-element records fit the LDS of a compute unit
+    // (up to about 32 x 32 pixels: the SPP map of inputs up to 1024 x 1024)
+    const size_t lds = (size_t)h * w * (dtype == ODAMD_DTYPE_F32 ? spp_gather_bytes_per_pixel<ODAMD_DTYPE_F32>()
+                                                                  : spp_gather_bytes_per_pixel<ODAMD_DTYPE_BF16>());
+    if (aligned && w <= 255 && (size_t)h * w <= 65535 && lds <= 160 * 1024 && batch <= 65535) {
+        const dim3 grid(c / per, batch);
+        if (dtype == ODAMD_DTYPE_F32) {
+            auto k = spp_bwd_gather_kernel<ODAMD_DTYPE_F32>;
+            if (odamd_ensure_lds((const void*)k, lds) != hipSuccess) return (int)hipGetLastError();
+            k<<<grid, 256, lds, (hipStream_t)stream>>>((const char*)x, x_ld, (const char*)dy5, (const char*)dy9, (const char*)dy13, dy_ld,
+                                                        (char*)dx, dx_ld, h, w);
+        } else {
+            auto k = spp_bwd_gather_kernel<ODAMD_DTYPE_BF16>;
+            if (odamd_ensure_lds((const void*)k, lds) != hipSuccess) return (int)hipGetLastError();
+            k<<<grid, 256, lds, (hipStream_t)stream>>>((const char*)x, x_ld, (const char*)dy5, (const char*)dy9, (const char*)dy13, dy_ld,
+                                                        (char*)dx, dx_ld, h, w);
         }
-        return ODAMD_OK;
+        return (int)hipGetLastError();
     }
-    if ((c & 7) || (x_ld & 7) || (dy_ld & 7) || (dx_ld & 7) || ((uintptr_t)x & 15) || ((uintptr_t)dy5 & 15) || ((uintptr_t)dy9 & 15) ||
-        ((uintptr_t)dy13 & 15) || ((uintptr_t)dx & 15))
-        return ODAMD_E_ALIGN;
-    spp_bwd_bf16_kernel<<<dim3(c / 8, batch), 256, spp_lds, (hipStream_t)stream>>>((const char*)x, x_ld, (const char*)dy5, (const char*)dy9,
-                                                                                  (const char*)dy13, dy_ld, (char*)dx, dx_ld, h, w);
-    return (int)hipGetLastError();
+    // larger planes (or unaligned tensors): the three pools one after the other with float atomics (the sums are then
+    // repeatable only up to the order of the additions)
+    const void* dys[3] = {dy5, dy9, dy13};
+    const int ks[3] = {5, 9, 13};
+    for (int i = 0; i < 3; ++i) {
+        const int rc = odamd_maxpool_s1_backward(x, x_ld, dys[i], dy_ld, dx, dx_ld, batch, h, w, c, ks[i], dtype, stream);
+        if (rc) return rc;
+    }
+    return ODAMD_OK;
 }
 
 int odamd_upsample2_backward(const void* dy, int dy_ld, void* dx, int dx_ld, int batch, int h, int w, int c, int dtype,

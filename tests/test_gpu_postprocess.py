@@ -103,6 +103,27 @@ def test_candidate_counts_far_below_the_padded_row_count(pp):
         assert np.array_equal(out[b][0], rows)
 
 
+@pytest.mark.parametrize('dense,cthr,ithr', [(True, 0.0, 0.5), (False, 0.0, 0.3)])
+def test_greedy_pass_over_several_compacted_chunks(pp, dense, cthr, ithr):
+    """64 images of 17 000 candidates each (32 768 sort keys; a batch of 64 gets mask chunks of 4 096 rows): the greedy
+    pass runs five times over a candidate list that is compacted in between (decided rows and suppressed candidates
+    dropped, the rest moved up).  Three distinct images are repeated through the batch; kept indices and rows of every
+    copy equal the oracle's, and the candidate count reported is the one before compaction."""
+    n, ncls, batch = 17000, 1, 64
+    distinct = [_synthetic_pred(700 + b, n, ncls, 640, dense) for b in range(3)]
+    want = [opost.predict_decode(p, (640, 640, 3), 640, cthr, ithr) for p in distinct]
+    preds = np.stack([distinct[b % 3] for b in range(batch)])
+    res = pp.postprocess(torch.from_numpy(preds).cuda(), cthr, ithr)
+    cand = res.cand.cpu().numpy()
+    out = res.per_image()
+    for b in range(batch):
+        rows, kept = want[b % 3]
+        assert cand[b] == len(opost.filter_indices(distinct[b % 3], cthr)[1])
+        assert np.array_equal(out[b][1], kept), f'image {b}'
+        assert np.array_equal(out[b][0], rows)
+    assert 0 < len(want[0][1]) < n
+
+
 @pytest.mark.parametrize('ithr', [0.3, 0.5, 0.7, 0.02, 0.98, 0.0, 1.0, 1.5])
 def test_nms_mixed_scales_and_irregular_boxes(pp, ithr):
     """Boxes from 2 to 400 pixels (log-uniform, all shapes) in overlapping clusters, with zero, negative,

@@ -440,16 +440,12 @@ def test_backward_write_modes_and_weight_layouts_agree(te, kind, kw, shape, dtyp
         torch.cuda.synchronize()
         results.append([y.cpu(), plan.dx_nchw.cpu().clone(), state.grad.cpu().clone()])
     base, added, plain = results
-    # the float32 backward of the stride-1 max pools adds with float atomics: repeatable to rounding only
-    exact = not (kind == 'sppcspc' and dtype == 'f32')
+    # no kernel of the step adds with atomics (the stride-1 max pools of sppcspc gather in a fixed order): bitwise equal
     for name, a, b2 in zip(('y', 'dx', 'grad'), base, added):
-        if exact:
-            assert torch.equal(a, b2), (name, int((a != b2).sum()), float((a - b2).abs().max()), float(a.abs().max()))
-        else:
-            assert float((a - b2).abs().max()) <= 1e-5 * float(a.abs().max()), name
+        assert torch.equal(a, b2), (name, int((a != b2).sum()), float((a - b2).abs().max()), float(a.abs().max()))
     for a, b2 in zip(base, plain):
         scale = float(a.abs().max()) + 1e-30
-        assert float((a - b2).abs().max()) <= (2e-2 if dtype == 'bf16' else (0.0 if exact else 1e-5)) * scale
+        assert float((a - b2).abs().max()) <= (2e-2 if dtype == 'bf16' else 0.0) * scale
 
 
 def _oracle_block_train(kind, mod, x, gy, act_bf16=False):
@@ -469,14 +465,19 @@ def _oracle_block_train(kind, mod, x, gy, act_bf16=False):
     return y.detach(), xr.grad, {k[1:]: v.grad for k, v in sd.items() if v.requires_grad}
 
 
-@pytest.mark.parametrize('h,w,c', [(20, 20, 16), (13, 17, 8), (32, 32, 24)])
-def test_spp_backward_fused_with_ties(h, w, c):
-    """odamd_spp_backward (bf16: one launch for the k = 5, 9, 13 pools of model/layer.py:215-217) on coarsely quantised
+@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+@pytest.mark.parametrize('h,w,c', [(20, 20, 16), (13, 17, 8), (32, 32, 24), (40, 40, 8)])
+def test_spp_backward_fused_with_ties(h, w, c, dtype):
+    """odamd_spp_backward (one launch for the k = 5, 9, 13 pools of model/layer.py:215-217) on coarsely quantised
     inputs with ties everywhere: each window's gradient goes to its first maximum in row-major order, like torch; the
-    three contributions are summed in float32 and rounded to bf16 once."""
+    three contributions are summed in float32 (and rounded to bf16 once).  Planes that fit the LDS take the fixed-order
+    gather (no atomics: two runs are bitwise equal); 40 x 40 takes the three separate launches."""
     from objectdetection_amd._lib import lib, check
+    if dtype == 'bf16' and h * w > 1024:
+        pytest.skip('bf16 planes beyond 1024 pixels are not supported by the pool backward kernels')
     g = torch.Generator().manual_seed(9)
     b = 3
+    tdt, code, es = (torch.bfloat16, 1, 2) if dtype == 'bf16' else (torch.float32, 0, 4)
     x = (torch.randn(b, c, h, w, generator=g) * 2).round() / 2
     xr = x.clone().requires_grad_(True)
     gys, total = [], 0
@@ -486,18 +487,24 @@ def test_spp_backward_fused_with_ties(h, w, c):
         total = total + (y * gy).sum()
         gys.append(gy)
     total.backward()
-    xg = x.permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
-    gyg = torch.cat([t.permute(0, 2, 3, 1) for t in gys], dim=3).contiguous().bfloat16().cuda()      # three slices of one buffer
-    base = (torch.randn(b, h, w, c, generator=g)).bfloat16().cuda()
-    dx = base.clone()
+    xg = x.permute(0, 2, 3, 1).contiguous().to(tdt).cuda()
+    gyg = torch.cat([t.permute(0, 2, 3, 1) for t in gys], dim=3).contiguous().to(tdt).cuda()      # three slices of one buffer
+    base = ((torch.randn(b, h, w, c, generator=g) * 8).round() / 8).to(tdt).cuda()
     p0 = gyg.data_ptr()
-    check(lib.odamd_spp_backward(xg.data_ptr(), c, p0, p0 + 2 * c, p0 + 4 * c, 3 * c, dx.data_ptr(), c, b, h, w, c, 1, None))
-    torch.cuda.synchronize()
-    want = (base.float().cpu() + xr.grad.permute(0, 2, 3, 1)).bfloat16().float()
-    if h * w * 8 * 18 <= 64 * 1024:      # the one-launch form
-        assert torch.equal(dx.float().cpu(), want)
+    runs = []
+    for _ in range(2):
+        dx = base.clone()
+        check(lib.odamd_spp_backward(xg.data_ptr(), c, p0, p0 + es * c, p0 + 2 * es * c, 3 * c, dx.data_ptr(), c, b, h, w, c, code, None))
+        torch.cuda.synchronize()
+        runs.append(dx.float().cpu())
+    want = (base.float().cpu() + xr.grad.permute(0, 2, 3, 1)).to(tdt).float()
+    one_launch = h * w * (8 * 19 if dtype == 'bf16' else 4 * 25) <= 160 * 1024 and w <= 255
+    if one_launch or dtype == 'f32':     # exact sums of quantised values in float32, one rounding
+        assert torch.equal(runs[0], want)
     else:                                # three launches: dx is rounded to bf16 after each of them
-        assert float((dx.float().cpu() - want).abs().max()) <= 2.0 ** -6 * float(want.abs().max())
+        assert float((runs[0] - want).abs().max()) <= 2.0 ** -6 * float(want.abs().max())
+    if one_launch:
+        assert torch.equal(runs[0], runs[1])
 
 
 @pytest.mark.parametrize('kind,kw,shape', [
