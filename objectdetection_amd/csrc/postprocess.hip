@@ -774,27 +774,6 @@ iou_mask_kernel(const float4* __restrict__ sbox, const float4* __restrict__ colp
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// IoU mask with area windows.  A pair can only reach the threshold when the two areas are within
-// a factor (1 + thr) / thr of each other, and the cheap keep test of iou_mask_kernel already proves
-// it: inter <= min(ea_row, ea_col) (ea = product of the rounded extents, see below), so
-//     ea_col < k_lo * area_row            or            ea_row < k_lo * area_col
-// implies inter < k_lo * area_row + k_lo * area_col, the "surely survives" decision.  To make that
-// usable for whole waves, the rows of a wave are chosen by size: within blocks of AREA_BLOCK sorted
-// positions the rows are listed by ascending area (area_order_kernel); a wave takes 64 consecutive
-// entries, i.e. rows of similar area from a 1024-wide score window, and for every column tile a ballot
-// over the column boxes keeps only the columns that some row of the wave could meet at the threshold and
-// packs them into the wave's LDS slice.  The surviving columns (about half on mixed-size candidates) run
-// through the same common-case test as in iou_mask_kernel, eight at a time; everything else (irregular boxes, second look, exact
-// arithmetic) is unchanged, and so are the bits written: the scan kernel cannot tell the difference.
-// The price: the strict upper triangle is only exploited per block (column tiles before the rows' block
-// are skipped, the block's own 16 tiles are computed for all rows and masked per lane).
-//   inter <= ea: dx = fl(min(ax2, cx2) - max(ax, cx)) <= fl(ax2 - ax) = ew by monotone rounding, same for dy,
-//   and for dx, dy > 0 fl(dx * dy) <= fl(ew * eh); with dx <= 0 or dy <= 0 the product is <= 0.
-//   Likewise inter <= fl(min(ew_row, ew_col) * min(eh_row, eh_col)), which also separates shapes:
-//   a column is dropped when that bound, taken with the widest and the tallest row of the wave, stays
-//   below fl(min_row(k_lo * area_row) + k_lo * area_col) <= the pair's own threshold.
-// ------------------------------------------------------------------------------------------
 // Between two chunks of the greedy pass: rows [0, r1) of the sorted candidate list are decided (kept ones are in the
 // output already), and every later candidate whose bit in `removed` is set will never be looked at again.  The
 // survivors move to the front of the other copy of the list (order preserved, so the greedy result is the same), the
@@ -856,29 +835,72 @@ compact_live_kernel(const float4* __restrict__ sbox_in, const int* __restrict__ 
     if (tid == 0) count[b] = total;
 }
 
-constexpr int AREA_BLOCK = 1024;
+// ------------------------------------------------------------------------------------------
+// IoU mask with area windows.  A pair can only reach the threshold when the two areas are within
+// a factor (1 + thr) / thr of each other, and the cheap keep test of iou_mask_kernel already proves
+// it: inter <= min(ea_row, ea_col) (ea = product of the rounded extents, see below), so
+//     ea_col < k_lo * area_row            or            ea_row < k_lo * area_col
+// implies inter < k_lo * area_row + k_lo * area_col, the "surely survives" decision.  To make that
+// usable for whole waves, the rows of a wave are chosen by size AND place: within blocks of AREA_BLOCK sorted
+// positions the rows are listed by (half-octave area class, Morton code of the centre) (area_order_kernel); a wave
+// takes 64 consecutive entries, i.e. rows of similar area from one region of the image, and for every column tile a
+// ballot over the column boxes keeps only the columns that some row of the wave could meet at the threshold - by
+// area, by shape, and by lying inside the bounding box of the wave's rows at all (a column outside it has
+// intersection 0 with every row, which never reaches a positive threshold) - and
+// packs them into the wave's LDS slice.  The surviving columns (about half on mixed-size candidates) run
+// through the same common-case test as in iou_mask_kernel, eight at a time; everything else (irregular boxes, second look, exact
+// arithmetic) is unchanged, and so are the bits written: the scan kernel cannot tell the difference.
+// The price: the strict upper triangle is only exploited per wave (column tiles before the wave's first row are
+// skipped, the rest is computed for all its rows and masked per lane).  Measured at 11 000 candidates per image: the
+// bounding box takes 10 % off the kernel (what is left is the per-tile work: staging, ballots, packing); blocks of
+// 4096 rows (seven waves per size class and image region instead of two) gain nothing more and cost a longer sort.
+//   inter <= ea: dx = fl(min(ax2, cx2) - max(ax, cx)) <= fl(ax2 - ax) = ew by monotone rounding, same for dy,
+//   and for dx, dy > 0 fl(dx * dy) <= fl(ew * eh); with dx <= 0 or dy <= 0 the product is <= 0.
+//   Likewise inter <= fl(min(ew_row, ew_col) * min(eh_row, eh_col)), which also separates shapes:
+//   a column is dropped when that bound, taken with the widest and the tallest row of the wave, stays
+//   below fl(min_row(k_lo * area_row) + k_lo * area_col) <= the pair's own threshold.
+// ------------------------------------------------------------------------------------------
+constexpr int AREA_BLOCK = 1024;          // granule of the row order (chunks are made of whole blocks)
 
+// bits 0..9 of v spread to the even bit positions
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+// Row order of the windowed mask kernel: within blocks of BLOCK sorted positions, ascending (area class, Morton code
+// of the box centre in 16-pixel cells, position).  The order only decides which rows share a wave: any order is correct.
+template <int BLOCK>
 __global__ void __launch_bounds__(256)
 area_order_kernel(const float4* __restrict__ sbox, const int* __restrict__ count, int n_pad, int* __restrict__ perm) {
-    __shared__ u64 s[AREA_BLOCK];
-    const int b = blockIdx.y, base = blockIdx.x * AREA_BLOCK;
+    __shared__ u64 s[BLOCK];
+    const int b = blockIdx.y, base = blockIdx.x * BLOCK;
     const int n = count ? min(count[b], n_pad) : n_pad;
-    for (int t = threadIdx.x; t < AREA_BLOCK; t += 256) {
+    for (int t = threadIdx.x; t < BLOCK; t += 256) {
         const int gi = base + t;
         u64 key = ~0ull;
         if (gi < n) {
-            const BoxEx e = box_ex(sbox[(size_t)b * n_pad + gi]);
-            // positive floats order like their bit patterns; irregular boxes go last
-            const uint32_t ab = e.special != 0.0f ? 0x7F800000u : __float_as_uint(e.area);
-            key = ((u64)ab << 32) | (uint32_t)gi;
+            const float4 c = sbox[(size_t)b * n_pad + gi];
+            const BoxEx e = box_ex(c);
+            // positive floats order like their bit patterns: exponent and first mantissa bit = half-octave classes;
+            // irregular boxes go last
+            const uint32_t cls = e.special != 0.0f ? 0x1FFu : (__float_as_uint(e.area) >> 22);
+            const float cx = c.x + 0.5f * c.z, cy = c.y + 0.5f * c.w;
+            const uint32_t qx = (uint32_t)fminf(fmaxf(cx * 0.0625f, 0.0f), 1023.0f);   // NaN -> 0
+            const uint32_t qy = (uint32_t)fminf(fmaxf(cy * 0.0625f, 0.0f), 1023.0f);
+            const uint32_t morton = spread10(qx) | (spread10(qy) << 1);
+            key = ((u64)cls << 52) | ((u64)morton << 32) | (uint32_t)gi;
         }
         s[t] = key;
     }
     __syncthreads();
     if (base < n) {
-        for (int k = 2; k <= AREA_BLOCK; k <<= 1)
+        for (int k = 2; k <= BLOCK; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int t = threadIdx.x; t < AREA_BLOCK / 2; t += 256) {
+                for (int t = threadIdx.x; t < BLOCK / 2; t += 256) {
                     const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                     const int q = i | j;
                     const u64 x = s[i], y = s[q];
@@ -887,7 +909,7 @@ area_order_kernel(const float4* __restrict__ sbox, const int* __restrict__ count
                 __syncthreads();
             }
     }
-    for (int t = threadIdx.x; t < AREA_BLOCK; t += 256)
+    for (int t = threadIdx.x; t < BLOCK; t += 256)
         perm[(size_t)b * n_pad + base + t] = s[t] == ~0ull ? -1 : (int)(uint32_t)s[t];
 }
 
@@ -896,6 +918,7 @@ iou_mask_win_kernel(const float4* __restrict__ sbox, const float4* __restrict__ 
                     const int* __restrict__ perm, const int* __restrict__ count, const u64* __restrict__ removed,
                     int n_pad, int row_begin, int row_end, float thr, int corner_rule, u64* __restrict__ mask,
                     size_t mask_stride_img) {
+    constexpr int order_block = AREA_BLOCK;
     __shared__ float4 cols[MASK_WAVES][64];   // the tile's column boxes as they are (second look, exact arithmetic)
     // the surviving columns of the wave's tile, packed: (x, y, x2, y2), k_lo * area, original column
     __shared__ float4 pk_box[MASK_WAVES][72];
@@ -913,7 +936,6 @@ iou_mask_win_kernel(const float4* __restrict__ sbox, const float4* __restrict__ 
     const int ngroups = (nwords + MASK_WAVES - 1) / MASK_WAVES;
     const float4* boxes = sbox + (size_t)b * n_pad;
     for (int rg = (row_begin >> 6) + blockIdx.y; rg < rg_end; rg += gridDim.y) {
-        const int tile0 = (rg * 64 / AREA_BLOCK) * (AREA_BLOCK / 64);   // first column tile of the rows' block
         const int i = perm[(size_t)b * n_pad + rg * 64 + lane];         // sorted position of this lane's row, or -1
         bool live = i >= 0;
         if (live) live = !((removed[(size_t)b * words + (i >> 6)] >> (i & 63)) & 1ull);
@@ -928,13 +950,26 @@ iou_mask_win_kernel(const float4* __restrict__ sbox, const float4* __restrict__ 
         float wmax = live ? (ae.x2 - a.x) * (ae.y2 - a.y) : -__builtin_inff();
         float wmax_w = live ? ae.x2 - a.x : -__builtin_inff();     // widest and tallest row (rounded extents)
         float wmax_h = live ? ae.y2 - a.y : -__builtin_inff();
+        // bounding box of the wave's rows (only used when every live row is regular) and its first row
+        float bx0 = live ? a.x : __builtin_inff(), by0 = live ? a.y : __builtin_inff();
+        float bx1 = live ? ae.x2 : -__builtin_inff(), by1 = live ? ae.y2 : -__builtin_inff();
+        int i_min = live ? i : 0x7fffffff;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             wmin = fminf(wmin, __shfl_xor(wmin, o));
             wmax = fmaxf(wmax, __shfl_xor(wmax, o));
             wmax_w = fmaxf(wmax_w, __shfl_xor(wmax_w, o));
             wmax_h = fmaxf(wmax_h, __shfl_xor(wmax_h, o));
+            bx0 = fminf(bx0, __shfl_xor(bx0, o));
+            by0 = fminf(by0, __shfl_xor(by0, o));
+            bx1 = fmaxf(bx1, __shfl_xor(bx1, o));
+            by1 = fmaxf(by1, __shfl_xor(by1, o));
+            i_min = min(i_min, __shfl_xor(i_min, o));
         }
+        // column tiles before the wave's first live row hold no later box; a wave without live rows still writes
+        // its rows' (zero) words from the block's first tile on, as the scan of those rows' tiles reads them
+        const int blk0 = (rg * 64 / order_block) * (order_block / 64);
+        const int tile0 = live_mask ? max(blk0, i_min >> 6) : blk0;
         for (int grp = tile0 / MASK_WAVES + blockIdx.x; grp < ngroups; grp += gridDim.x) {
             const int ct = __builtin_amdgcn_readfirstlane(grp * MASK_WAVES + wave);   // column tile (wave-uniform)
             if (ct >= nwords) continue;
@@ -952,7 +987,8 @@ iou_mask_win_kernel(const float4* __restrict__ sbox, const float4* __restrict__ 
             // different shape are dropped as well
             const float cew = cp.z - cp.x, ceh = cp.w - cp.y;
             const bool keep_col = cvalid && !(cew * ceh < wmin) && !(wmax < ck) &&
-                                  !(fminf(wmax_w, cew) * fminf(wmax_h, ceh) < wmin + ck);
+                                  !(fminf(wmax_w, cew) * fminf(wmax_h, ceh) < wmin + ck) &&
+                                  !(cp.z < bx0) && !(cp.x > bx1) && !(cp.w < by0) && !(cp.y > by1);
             const u64 compat = __ballot(keep_col);
             const int ncompat = __popcll(compat);
             if (keep_col) {
@@ -1539,7 +1575,8 @@ int run_nms(const Workspace& w, int* count, int batch, int rows, int n_pad, floa
     const int r1 = w.chunk_rows < n_pad ? w.chunk_rows : n_pad;
     for (int r0 = 0; r0 < r_end; r0 += w.chunk_rows) {
         pack_cols_kernel<<<dim3((n_pad + 255) / 256, batch), 256, 0, st>>>(sbox, count, n_pad, iou_thr, w.colpk, w.colk);
-        if (windowed) area_order_kernel<<<dim3(n_pad / AREA_BLOCK, batch), 256, 0, st>>>(sbox, count, n_pad, w.perm);
+        // the pass handles rows [0, r1) only: their blocks alone are ordered
+        if (windowed) area_order_kernel<AREA_BLOCK><<<dim3(r1 / AREA_BLOCK, batch), 256, 0, st>>>(sbox, count, n_pad, w.perm);
         const int gx = (words + MASK_WAVES - 1) / MASK_WAVES, gy = r1 / 64;
         // the windowed kernel does its per-row-group set-up once per workgroup row: more rows, fewer column strides
         // (about 256 workgroups per image either way)
