@@ -426,7 +426,7 @@ def main():
         # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); null when the file is absent
         traffic = None
         try:
-            for name in ('r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
+            for name in ('r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_pmc_traffic.json'):
                 path = os.path.join(ROOT, 'profiles', name)
                 if os.path.exists(path):
                     with open(path) as fh:

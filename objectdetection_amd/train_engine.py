@@ -55,9 +55,30 @@ def _stream():
 class FlatState:
     """Flat float32 storage for parameters (+grad, Adam moments, EMA) and BN running buffers."""
 
+    LAYOUT = 2      # version of the order below (an optimizer state saved under another order does not fit)
+
     def __init__(self, model):
         dev = next(model.parameters()).device
         params = [p for p in model.parameters()]
+        # The two 1x1 cbs blocks at the head of an elan / elan_h block read the same tensor and write adjacent channel
+        # ranges (model/layer.py:75-76, :110-111): with their tensors stored back to back (weights, BN weights, BN
+        # biases, running means, running variances) the pair is ONE cbs of the summed width to every kernel of the
+        # training step (see TrainPlan._fuse_siblings).
+        self.sibling_pairs = sibling_pairs(model)
+        first = {id(a.conv.weight): (a, b) for a, b in self.sibling_pairs}
+        handled, order = set(), []
+        for p in params:
+            if id(p) in handled:
+                continue
+            if id(p) in first:
+                a, b = first[id(p)]
+                group = [a.conv.weight, b.conv.weight, a.bn.weight, b.bn.weight, a.bn.bias, b.bn.bias]
+                order += group
+                handled.update(id(q) for q in group)
+            else:
+                order.append(p)
+        assert len(order) == len(params)
+        params = order
         self.offsets, n = {}, 0
         for p in params:
             self.offsets[id(p)] = n
@@ -76,6 +97,20 @@ class FlatState:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
                 _register_flat(p, self)                # a block asked to train on its own finds its network's storage
         bufs = [b for b in model.buffers() if b.dtype.is_floating_point]
+        firstb = {id(a.bn.running_mean): (a, b) for a, b in self.sibling_pairs}
+        handled, order = set(), []
+        for t in bufs:
+            if id(t) in handled:
+                continue
+            if id(t) in firstb:
+                a, b = firstb[id(t)]
+                group = [a.bn.running_mean, b.bn.running_mean, a.bn.running_var, b.bn.running_var]
+                order += group
+                handled.update(id(q) for q in group)
+            else:
+                order.append(t)
+        assert len(order) == len(bufs)
+        bufs = order
         self.buf_offsets, nb = {}, 0
         for b in bufs:
             self.buf_offsets[id(b)] = nb
@@ -121,6 +156,20 @@ class FlatState:
 
     def grad_ptr(self, p):
         return self.grad.data_ptr() + 4 * self.offsets[id(p)]
+
+
+def sibling_pairs(model):
+    """(cbs0, cbs1) of every elan / elan_h block whose two head convolutions can run as one: same input width, 1x1,
+    widths that keep every tensor of the pair 16-byte aligned behind its sibling."""
+    from .model import layer
+    out = []
+    for m in model.modules():
+        if isinstance(m, (layer.elan, layer.elan_h)):
+            a, b = m.cbs0, m.cbs1
+            if (a.conv.in_channels == b.conv.in_channels and a.conv.kernel_size == (1, 1) and b.conv.kernel_size == (1, 1)
+                    and a.conv.out_channels % 4 == 0 and a.conv.weight.numel() % 4 == 0):
+                out.append((a, b))
+    return out
 
 
 def _gloo_with_gpu_tensor(t, group=None):
@@ -435,6 +484,45 @@ class TrainPlan:
         self.tdt = torch.float32 if dtype == F32 else torch.bfloat16     # activations, gradients, packed weights
         self._lower()
 
+    FUSE_SIBLINGS = True      # switch for tests, which compare both settings
+
+    def _fuse_siblings(self, ops):
+        """Two consecutive 1x1 cbs ops on the same input whose outputs are adjacent channel ranges of one buffer and
+        whose parameters, gradients and BatchNorm buffers are adjacent in the flat state (FlatState orders the pairs
+        that way) become ONE op of the summed width: one convolution, one BatchNorm (statistics are per channel), one
+        data gradient that reads both gradients at once, one weight gradient."""
+        if not self.FUSE_SIBLINGS:
+            return ops
+        st = self.state
+        pairs = {id(a): b for a, b in getattr(st, 'sibling_pairs', [])}
+        out, i = [], 0
+        while i < len(ops):
+            a = ops[i]
+            b = ops[i + 1] if i + 1 < len(ops) else None
+            ok = (b is not None and a['kind'] == 'conv' and b['kind'] == 'conv' and a['x'] is b['x'] and pairs.get(id(a['mod'])) is b['mod']
+                  and a['k'] == 1 and b['k'] == 1 and a['s'] == 1 and b['s'] == 1 and not a['pool'] and not b['pool']
+                  and a['x'].cphys == a['x'].c
+                  and a['y'].buf == b['y'].buf and a['y'].c == a['y'].cphys and len(a['y'].segments) == 1
+                  and len(b['y'].segments) == 1 and b['y'].c == b['y'].cphys and b['y'].c0 == a['y'].c0 + a['y'].cphys)
+            if ok:
+                ma, mb = a['mod'], b['mod']
+                for ta, tb in ((ma.conv.weight, mb.conv.weight), (ma.bn.weight, mb.bn.weight), (ma.bn.bias, mb.bn.bias)):
+                    ok = ok and st.offsets[id(tb)] == st.offsets[id(ta)] + ta.numel()
+                for ta, tb in ((ma.bn.running_mean, mb.bn.running_mean), (ma.bn.running_var, mb.bn.running_var)):
+                    ok = ok and st.buf_offsets[id(tb)] == st.buf_offsets[id(ta)] + ta.numel()
+            if ok:
+                ya, yb = a['y'], b['y']
+                f = dict(a)
+                f['mods'] = [ma, mb]
+                f['cout'] = ya.c + yb.c
+                f['y'] = Act(ya.buf, ya.c0, [(0, ya.c + yb.c)], ya.h, ya.w, ya.align)
+                out.append(f)
+                i += 2
+            else:
+                out.append(a)
+                i += 1
+        return out
+
     # ---- helpers ---------------------------------------------------------------------------
     def _aptr(self, act):
         return self.bufs[act.buf].data_ptr() + act.c0 * self.es
@@ -456,6 +544,7 @@ class TrainPlan:
                 ops.append(dict(kind='maxpool2', x=op['x'], y=pooled))
                 op = dict(op, x=pooled, pool=False)
             ops.append(op)
+        ops = self._fuse_siblings(ops)
         self.ops = ops
         # activation buffers and their gradients (one pool, zeroed once per step)
         self.bufs = [torch.zeros((B, h, w, c), dtype=self.tdt, device=dev) for c, h, w in pb.buffers]
@@ -486,7 +575,7 @@ class TrainPlan:
             kind = op['kind']
             if kind in ('conv', 'first'):
                 m = op['mod']
-                cout = m.conv.out_channels
+                cout = op.get('cout', m.conv.out_channels)      # a fused sibling pair: the summed width
                 cphys = _round_up(cout, self.pb.align)
                 y_act = op['y']
                 ho, wo = y_act.h, y_act.w
@@ -583,7 +672,7 @@ class TrainPlan:
         d.w = w.data_ptr()
         d.fwd = fwd.data_ptr()
         d.bwd = bwd.data_ptr() if bwd is not None else None
-        d.cout, d.cin, d.k = w.shape[0], w.shape[1], w.shape[2]
+        d.cout, d.cin, d.k = cout, w.shape[1], w.shape[2]       # cout: of a fused sibling pair, whose weights follow `w`
         d.cin_phys = x_act.cphys if x_act is not None else w.shape[1]
         d.cout_phys = _round_up(cout, self.pb.align)
         segs = x_act.segments if x_act is not None else [(0, w.shape[1])]
@@ -634,7 +723,7 @@ class TrainPlan:
             kind = op['kind']
             if kind in ('conv', 'first'):
                 m = op['mod']
-                cout = m.conv.out_channels
+                cout = op.get('cout', m.conv.out_channels)
                 raw = op['raw']
                 cphys = raw.shape[3]
                 k = m.conv.kernel_size[0]
@@ -661,7 +750,8 @@ class TrainPlan:
                                          x.w, n, cout, k, op['s'], self.dtype], 'wgrad', ('columns', m.conv.weight, src, n)))
                             src += n
                     bwd.append((lib.odamd_conv_forward, [C.byref(op['dgrad_desc'])], 'dgrad', None))
-                bwd.append(('mark', (m.conv.weight, m.bn.weight, m.bn.bias), 'mark', None))
+                bwd.append(('mark', tuple(t for q in op.get('mods', [m]) for t in (q.conv.weight, q.bn.weight, q.bn.bias)),
+                            'mark', None))
             elif kind == 'head':
                 m, x = op['mod'], op['x']
                 cout = m.output.out_channels

@@ -57,6 +57,42 @@ def test_block_train_step_matches_reference(te, golden, tag):
             assert rel_err(b.cpu().numpy(), g[f'{tag}.buf.{n}']) < 1e-5, n
 
 
+@pytest.mark.parametrize('tag', ['elan', 'elan_h'])
+def test_sibling_fusion_of_the_training_plan(te, golden, tag):
+    """The two 1x1 cbs blocks at the head of elan / elan_h run as one op of the summed width in the training plan
+    (their tensors are adjacent in the flat state).  Both forms meet the reference fixture, and the fused plan has one
+    convolution, one BatchNorm and one weight gradient fewer in each direction."""
+    g = golden('blocks.npz')
+    make, xn, shape = _block_cases()[tag]
+    counts = {}
+    for fuse in (True, False):
+        te.TrainPlan.FUSE_SIBLINGS = fuse
+        try:
+            mod = make()
+            patterns.fill_state_dict(mod)
+            mod = mod.cuda().train()
+            state = te.FlatState(mod)
+            assert len(state.sibling_pairs) == 1
+            plan = te.TrainPlan(mod, state, shape[0], shape[2], block_input=shape[1:])
+        finally:
+            te.TrainPlan.FUSE_SIBLINGS = True
+        counts[fuse] = (sum(1 for f in plan.fwd if f[2] == 'conv'), sum(1 for f in plan.bwd if f[2] == 'wgrad'))
+        x = patterns.wave(xn, shape, 1.0).cuda()
+        y = plan.forward(x)
+        assert rel_err(y.cpu().numpy(), g[f'{tag}.train']) < 1e-4
+        plan.gout_nchw.copy_(patterns.wave(tag + '.gy', tuple(y.shape), 1.0).cuda())
+        state.grad.zero_()
+        plan.backward(x)
+        torch.cuda.synchronize()
+        assert rel_err(plan.dx_nchw.cpu().numpy(), g[f'{tag}.dx']) < 1e-4
+        for n, p in mod.named_parameters():
+            assert rel_err(p.grad.cpu().numpy(), g[f'{tag}.grad.{n}']) < 2e-4, (fuse, n)
+        for n, b in mod.named_buffers():
+            if b.dtype.is_floating_point:
+                assert rel_err(b.cpu().numpy(), g[f'{tag}.buf.{n}']) < 1e-5, (fuse, n)
+    assert counts[True][0] == counts[False][0] - 1 and counts[True][1] == counts[False][1] - 1, counts
+
+
 def test_loss_matches_reference_fixture(te, golden):
     import ctypes as C
     from objectdetection_amd._lib import lib, check

@@ -8,7 +8,7 @@ import re
 
 _CG = {1: 'c32', 2: 'c64', 4: 'c128', 8: 'c128'}
 
-OTHER = ('conv_first2_kernel', 'conv_first_kernel', 'iou_mask_win_kernel', 'iou_mask_kernel', 'emit_heads_kernel',
+OTHER = ('conv_first2_kernel', 'conv_first_wide_kernel', 'conv_first_kernel', 'compact_live_kernel', 'iou_mask_win_kernel', 'iou_mask_kernel', 'emit_heads_kernel',
          'area_order_kernel', 'nms_scan_kernel', 'nms_resolve_kernel', 'filter_kernel', 'emit_rows_kernel',
          'bitonic_lds_kernel', 'bitonic_global_kernel', 'spp_pool3_kernel', 'spp_cascade_kernel', 'pack_cols_kernel',
          'upsample2_kernel')
