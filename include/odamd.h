@@ -212,6 +212,18 @@ int odamd_conv_weight_layout(const odamd_conv_desc* d, int* cout_groups, int* ch
 int odamd_conv_mp_supported(const odamd_conv_desc* pooled, const odamd_conv_desc* plain);
 int odamd_conv_mp_forward(const odamd_conv_desc* pooled, const odamd_conv_desc* plain, void* stream);
 
+/* Two chained 3x3 stride-1 cbs blocks in ONE launch: the 3x3 chains of elan (sequential2 -> sequential3,
+ * model/layer.py:74-81) and elan_h (cbs2 -> cbs3, cbs4 -> cbs5, model/layer.py:109-118), whose every link is also a
+ * slice of the block's concat.  `second` must read exactly what `first` writes (second->x == first->y, same x_ld /
+ * y_ld, batch, h, w_in); bf16, w_packed = 1 with the whole tensor as one block of fragments (the layout of
+ * odamd_conv_weight_layout with G = 1, CB = cin * 2), folded BatchNorm constants on both; 32 or 64 input channels, 32 channels
+ * between and after the two.  Both outputs are written (the first one is a concat slice too); the second convolution
+ * reads the first one's tile, halo included, from LDS.  odamd_conv_chain_pair_supported returns 1 where the fused
+ * form exists (the descriptors' pointers take part: alignment and the x / y identity), and the forward call gives
+ * the same results as the two odamd_conv_forward calls; otherwise it returns ODAMD_E_SHAPE. */
+int odamd_conv_chain_pair_supported(const odamd_conv_desc* first, const odamd_conv_desc* second);
+int odamd_conv_chain_pair_forward(const odamd_conv_desc* first, const odamd_conv_desc* second, void* stream);
+
 /* First layer: float32 NCHW image (B,3,H,W) -> NHWC activations; replaces cbs0 of
  * yolov7.forward (model/yolov7.py:114).  w: [cout][ky][kx][3] float32; scale/shift may both be
  * NULL (raw convolution for train-mode BatchNorm); act: 0 none, 1 SiLU. */

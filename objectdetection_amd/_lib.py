@@ -74,6 +74,8 @@ SIGNATURES = {
     'odamd_conv_weight_layout': (c_int, [C.POINTER(ConvDesc), C.POINTER(c_int), C.POINTER(c_int)]),
     'odamd_conv_mp_supported': (c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     'odamd_conv_mp_forward': (c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), c_void_p]),
+    'odamd_conv_chain_pair_supported': (c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
+    'odamd_conv_chain_pair_forward': (c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), c_void_p]),
     'odamd_conv_first_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                          c_int, c_int, c_int, c_int, c_void_p]),
     'odamd_conv_first2_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -765,6 +765,7 @@ __device__ __attribute__((aligned(64))) const unsigned char g_zero_line[64] = {}
 #include "conv_s3.h"
 #include "conv_wres.h"
 #include "conv_mp.h"
+#include "conv_pair.h"
 
 // ------------------------------------------------------------------------------------------
 // first layer, float32 compute: float32 NCHW image, 3 input channels, 3x3 stride 1 -> NHWC
@@ -1988,6 +1989,59 @@ int dispatch_mp(const odamd_conv_desc* a, const odamd_conv_desc* b, hipStream_t 
     return ODAMD_E_SHAPE;
 }
 
+// ---- two chained 3x3 convolutions with 32 channels between and after them in one launch (conv_pair.h) ----------
+// `a`: the first convolution, `b`: the second, which reads exactly what `a` writes.
+bool chain_pair_ok(const odamd_conv_desc* a, const odamd_conv_desc* b) {
+    if (!a || !b) return false;
+    if (a->dtype != ODAMD_DTYPE_BF16 || b->dtype != ODAMD_DTYPE_BF16) return false;
+    if (a->ksize != 3 || b->ksize != 3 || a->stride != 1 || b->stride != 1) return false;
+    if (a->in_pool2 || b->in_pool2 || a->out_nchw_f32 || b->out_nchw_f32 || a->in_upzero2 || b->in_upzero2 || a->accumulate ||
+        b->accumulate || !a->w_packed || !b->w_packed || !a->scale || !a->shift || !b->scale || !b->shift)
+        return false;
+    if (b->x != a->y || b->x_ld != a->y_ld || a->batch != b->batch || a->h != b->h || a->w_in != b->w_in) return false;
+    if ((a->cin != 32 && a->cin != 64) || a->cout != 32 || b->cin != 32 || b->cout != 32) return false;
+    if (a->x_ld % 8 || a->y_ld % 8 || b->y_ld % 8 || a->x_ld < a->cin || a->y_ld < 32 || b->y_ld < 32) return false;
+    if (((uintptr_t)a->x & 15) || ((uintptr_t)a->y & 15) || ((uintptr_t)b->y & 15) || ((uintptr_t)a->w & 15) || ((uintptr_t)b->w & 15))
+        return false;
+    const long long npix = (long long)a->batch * a->h * a->w_in;
+    if (npix * a->y_ld * 2 >= (1ll << 31) || npix * b->y_ld * 2 >= (1ll << 31)) return false;
+    if ((long long)a->h * a->w_in >= (1ll << 24)) return false;
+    return true;
+}
+
+int launch_chain_pair(const odamd_conv_desc* a, const odamd_conv_desc* b, hipStream_t st) {
+    PairP p = {};
+    p.x = (const char*)a->x; p.w1 = (const char*)a->w; p.w2 = (const char*)b->w;
+    p.sc1 = a->scale; p.sh1 = a->shift; p.sc2 = b->scale; p.sh2 = b->shift;
+    p.y1 = (char*)a->y; p.y2 = (char*)b->y;
+    p.B = a->batch; p.H = a->h; p.W = a->w_in; p.x_ld = a->x_ld; p.y1_ld = a->y_ld; p.y2_ld = b->y_ld;
+    p.act1 = a->act; p.act2 = b->act;
+    p.tiles_x = (p.W + 15) / 16; p.tiles_y = (p.H + 15) / 16;
+    // vertical runs of tiles per workgroup (the weights are copied once per run), short enough to leave ~1000 workgroups
+    int seg = p.tiles_y;
+    while (seg > 1 && (long long)p.B * p.tiles_x * ((p.tiles_y + seg - 1) / seg) < 1024) seg = (seg + 1) / 2;
+    p.seg = seg;
+    p.runs_y = (p.tiles_y + seg - 1) / seg;
+    const long long nblocks = (long long)p.B * p.tiles_x * p.runs_y;
+    if (nblocks >= (1ll << 30)) return ODAMD_E_SHAPE;
+    p.nblocks = (int)nblocks;
+    const size_t npix = (size_t)p.B * p.H * p.W;
+    p.y1bytes = (unsigned)((npix - 1) * p.y1_ld * 2 + 64);
+    p.y2bytes = (unsigned)((npix - 1) * p.y2_ld * 2 + 64);
+    const int ks1 = a->cin / 16;
+    const size_t lds = (size_t)9 * ks1 * 1024 + 18 * 1024 + (size_t)PR_IN_BLOCKS * 2 * ks1 * 256 + 512;
+    if (ks1 == 2) {
+        auto k = conv_pair_kernel<2>;
+        if (odamd_ensure_lds((const void*)k, lds) != hipSuccess) return (int)hipGetLastError();
+        k<<<p.nblocks, 256, lds, st>>>(p);
+    } else {
+        auto k = conv_pair_kernel<4>;
+        if (odamd_ensure_lds((const void*)k, lds) != hipSuccess) return (int)hipGetLastError();
+        k<<<p.nblocks, 256, lds, st>>>(p);
+    }
+    return (int)hipGetLastError();
+}
+
 template <int DT>
 int dispatch_conv(const ConvP& p, int ks, int stride, hipStream_t st) {
     const int cin_bytes = p.Cin * Elem<DT>::SIZE;
@@ -2154,6 +2208,21 @@ int odamd_conv_mp_forward(const odamd_conv_desc* pooled, const odamd_conv_desc* 
     if (!mp_pair_ok(pooled, plain)) return ODAMD_E_SHAPE;
     if (((uintptr_t)pooled->y & 15) || ((uintptr_t)plain->y & 15)) return ODAMD_E_ALIGN;
     return dispatch_mp(pooled, plain, (hipStream_t)stream);
+}
+
+int odamd_conv_chain_pair_supported(const odamd_conv_desc* first, const odamd_conv_desc* second) {
+    ConvP pa, pb;
+    if (fill_conv_params(first, &pa, false) != ODAMD_OK || fill_conv_params(second, &pb, false) != ODAMD_OK) return 0;
+    return chain_pair_ok(first, second) ? 1 : 0;
+}
+
+int odamd_conv_chain_pair_forward(const odamd_conv_desc* first, const odamd_conv_desc* second, void* stream) {
+    ConvP pa, pb;
+    int rc = fill_conv_params(first, &pa, true);
+    if (rc) return rc;
+    if ((rc = fill_conv_params(second, &pb, true))) return rc;
+    if (!chain_pair_ok(first, second)) return ODAMD_E_SHAPE;
+    return launch_chain_pair(first, second, (hipStream_t)stream);
 }
 
 int odamd_conv_first_forward(const float* image, const float* w, const float* scale, const float* shift, void* y,

@@ -25,6 +25,7 @@ from ._lib import lib, check
 F32, BF16 = 0, 1
 FUSE_MP = True                # both 1x1 convolutions of an mp block in one launch (bf16 plans)
 FUSE_FIRST2 = True     # bf16 plans run cbs0 + cbs1 as one launch when the widths are 16 and 32
+FUSE_CHAIN = True      # two chained 3x3 convolutions with 32 channels between and after them in one launch (bf16 plans)
 SIDE_STREAMS = True    # side branches of a plan (heads, lateral 1x1 convolutions) run on a second HIP stream
 _TORCH_DT = {0: torch.float32, 1: torch.bfloat16}
 CH_ALIGN = 16            # channel granule of buffer slices in bf16 plans (f32 plans use 8)
@@ -229,7 +230,8 @@ class Plan:
         self._fuse_sibling_convs()
         used = set()
         for op in builder.ops:      # buffers no launch touches any more (fused away) are not allocated
-            parts = [op['pooled'], op['plain']] if op['kind'] == 'mp2' else [op]
+            parts = ([op['pooled'], op['plain']] if op['kind'] == 'mp2' else
+                     [op['first'], op['second']] if op['kind'] == 'c3pair' else [op])
             for a in [q.get(n) for q in parts for n in ('x', 'y')] + list(op.get('ys', [])):
                 if a is not None and not (op['kind'] == 'first2' and a is op.get('x')):
                     used.add(a.buf)
@@ -261,6 +263,7 @@ class Plan:
                 i += 1
         out = self._fuse_first_two(out)
         out = self._fuse_mp_pairs(out)
+        out = self._fuse_chain_pairs(out)
         self.b.ops = out
         self.b.convs = []
         for op in out:
@@ -268,6 +271,8 @@ class Plan:
                 self.b.convs.append(op)
             elif op['kind'] == 'mp2':
                 self.b.convs += [op['pooled'], op['plain']]
+            elif op['kind'] == 'c3pair':
+                self.b.convs += [op['first'], op['second']]
 
     def _fuse_mp_pairs(self, ops):
         """cbs1 (on the max-pooled input) and cbs2 (on the input itself) of an mp block (model/layer.py:139-145) read
@@ -285,6 +290,32 @@ class Plan:
                     and not b['pool'] and len(a['y'].segments) == 1 and len(b['y'].segments) == 1
                     and a['y'].c == a['y'].cphys and b['y'].c == b['y'].cphys):
                 out.append(dict(kind='mp2', pooled=a, plain=b))
+                i += 2
+            else:
+                out.append(a)
+                i += 1
+        return out
+
+    def _fuse_chain_pairs(self, ops):
+        """Two consecutive 3x3 stride-1 cbs blocks where the second reads what the first writes (the chains of elan,
+        model/layer.py:74-81, and elan_h, model/layer.py:109-118) become ONE launch in bf16 plans
+        (odamd_conv_chain_pair_forward) where the library has the fused form (decided in _build, which falls back to
+        two launches otherwise): the second convolution reads the first one's tile from LDS.  Only chains that start
+        from 32 channels: with 64 input channels the fused kernel measures behind the two launches (batch 64, 80 x 80:
+        76 us against 53 us), with 32 slightly ahead (160 x 160: 150 against 159 us; 80 x 80: 41 against 45 us)."""
+        if not FUSE_CHAIN or self.b.dtype != BF16:
+            return ops
+        out, i = [], 0
+        while i < len(ops):
+            a = ops[i]
+            b = ops[i + 1] if i + 1 < len(ops) else None
+            if (b is not None and a['kind'] == 'conv' and b['kind'] == 'conv' and b['x'] is a['y']
+                    and 'mods' not in a and 'mods' not in b and not a.get('side') and not b.get('side')
+                    and a['k'] == 3 and b['k'] == 3 and a['s'] == 1 and b['s'] == 1 and not a['pool'] and not b['pool']
+                    and a['mod'].conv.out_channels == 32 and b['mod'].conv.out_channels == 32
+                    and a['x'].cphys == 32 and len(a['y'].segments) == 1 and len(b['y'].segments) == 1
+                    and a['y'].c == a['y'].cphys and b['y'].c == b['y'].cphys):
+                out.append(dict(kind='c3pair', first=a, second=b))
                 i += 2
             else:
                 out.append(a)
@@ -432,6 +463,26 @@ class Plan:
                         self.launches.append((lib.odamd_conv_forward, [C.byref(d)], 'conv', None))
                         self.meta[len(self.launches) - 1] = meta
                         self.launch_op.append(sub)
+            elif kind == 'c3pair':
+                da, ma = self._conv_launch(op['first'], allow_packed=False)
+                db, mb = self._conv_launch(op['second'], allow_packed=False)
+                for d, sub in ((da, op['first']), (db, op['second'])):     # whole tensor as one block of fragments
+                    sub['frag'] = (1, sub['x'].cphys * self.es)
+                    d.w_packed = 1
+                if lib.odamd_conv_chain_pair_supported(C.byref(da), C.byref(db)):
+                    self.launches.append((lib.odamd_conv_chain_pair_forward, [C.byref(da), C.byref(db)], 'conv_chain_pair', None))
+                    y = op['first']['y']
+                    self.meta[len(self.launches) - 1] = dict(      # the tensor between the two is written, not read back
+                        kernel='conv3x3_pair', flops=ma['flops'] + mb['flops'],
+                        bytes=ma['bytes'] + mb['bytes'] - float(B * y.h * y.w * y.c * self.es),
+                        shape=ma['shape'] + '->' + mb['shape'].split('>')[1])
+                else:
+                    for sub in (op['first'], op['second']):
+                        sub.pop('frag')
+                        d, meta = self._conv_launch(sub)
+                        self.launches.append((lib.odamd_conv_forward, [C.byref(d)], 'conv', None))
+                        self.meta[len(self.launches) - 1] = meta
+                        self.launch_op.append(sub)
             elif kind == 'first':
                 m, y = op['mod'], op['y']
                 cout = m.conv.out_channels
@@ -512,9 +563,13 @@ class Plan:
                 reads = [op[k] for k in ('x',) if op.get(k) is not None]
                 if op['kind'] == 'mp2':
                     reads = [op['plain']['x']]
+                if op['kind'] == 'c3pair':
+                    reads = [op['first']['x']]
                 writes = [op[k] for k in ('y',) if op.get(k) is not None] + list(op.get('ys', []))
                 if op['kind'] == 'mp2':
                     writes = [op['pooled']['y'], op['plain']['y']]
+                if op['kind'] == 'c3pair':
+                    writes = [op['first']['y'], op['second']['y']]
                 for a in reads + writes:
                     if any(bf == a.buf and lo < a.c0 + a.cphys and a.c0 < hi for bf, lo, hi in pending):
                         self.join[i] = True

@@ -149,6 +149,89 @@ def test_fused_mp_pair_equals_separate_launches(od, in_, out_, shape):
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize('kind,kw,shape', [
+    ('elan', dict(in_=64, out_=128, n=1), (2, 64, 48, 48)),        # 32 -> 32 -> 32, whole tiles
+    ('elan', dict(in_=64, out_=128, n=1), (3, 64, 37, 53)),        # ragged tiles on both axes, one tile row taller than the run
+    ('elan_h', dict(in_=128, out_=64), (2, 128, 40, 56)),          # 64 -> 32 -> 32 and 32 -> 32 -> 32
+    ('elan_h', dict(in_=128, out_=64), (1, 128, 90, 21)),
+    ('elan', dict(in_=64, out_=128, n=1), (70, 64, 80, 80)),       # enough tiles for vertical runs of several tiles
+])
+def test_fused_chain_pair_equals_separate_launches(od, kind, kw, shape):
+    """odamd_conv_chain_pair_forward (two chained 3x3 convolutions in one launch, the tile between them in LDS) against
+    the two odamd_conv_forward launches it replaces, on the same weights and input.  Both paths round the first
+    convolution's result to bf16 before the second reads it; the float32 sums inside a convolution are taken in a
+    different order by the different kernels, so single bf16 results may differ by one unit in the last place."""
+    engine, layer, _ = od
+    x = torch.from_numpy(np.random.default_rng(11).standard_normal(shape).astype(np.float32)).cuda()
+    outs = []
+    engine.set_compute_dtype('bf16')
+    try:
+        for fuse in (True, False):
+            engine.FUSE_CHAIN = fuse
+            mod = getattr(layer, kind)(**kw)
+            patterns.fill_state_dict(mod)
+            mod = mod.cuda().eval()
+            outs.append(mod(x).float().cpu().numpy())
+            plans = engine.module_plans(mod)
+            kinds = [name for plan in plans.values() for _, _, name, _ in plan.launches]
+            assert ('conv_chain_pair' in kinds) == fuse, kinds
+            if fuse:      # the concat slices the pair wrote, against the f32 oracle of the block's input
+                ref = _oracle_block(kind, mod.cpu(), x.cpu()).numpy()
+                assert rel_err(outs[0], ref) < TOL['bf16']
+                assert_elementwise(outs[0], ref, TOL['bf16'])
+    finally:
+        engine.FUSE_CHAIN = True
+        engine.set_compute_dtype(None)
+    a, b = outs
+    scale = np.abs(b).max()
+    assert np.abs(a - b).max() <= 2e-2 * scale, np.abs(a - b).max() / scale
+    assert (a != b).mean() < 0.05, (a != b).mean()
+
+
+@pytest.mark.parametrize('cin,shape', [(64, (3, 37, 53)), (32, (2, 16, 16)), (64, (5, 64, 48))])
+def test_chain_pair_entry_point_against_two_launches(od, cin, shape):
+    """odamd_conv_chain_pair_forward through the C ABI on slices of one wide NHWC buffer (the concat addressing of the
+    ELAN blocks), 32 and 64 input channels, against odamd_conv_forward twice on the same buffers."""
+    import ctypes as C
+    from objectdetection_amd import _lib
+    engine = od[0]
+    B, H, W = shape
+    ld = cin + 64 + 32
+    rng = np.random.default_rng(3)
+    w1 = torch.from_numpy(rng.standard_normal((32, 3, 3, cin)).astype(np.float32) * 0.08).cuda().bfloat16()
+    w2 = torch.from_numpy(rng.standard_normal((32, 3, 3, 32)).astype(np.float32) * 0.1).cuda().bfloat16()
+    sc = [torch.from_numpy(rng.uniform(0.5, 1.5, 32).astype(np.float32)).cuda() for _ in range(2)]
+    sh = [torch.from_numpy(rng.uniform(-0.5, 0.5, 32).astype(np.float32)).cuda() for _ in range(2)]
+    x = torch.from_numpy(rng.standard_normal((B, H, W, ld)).astype(np.float32)).cuda().bfloat16()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def desc(buf, c0, y0, w, i, ci, packed):
+        d = _lib.ConvDesc()
+        d.x, d.y = buf.data_ptr() + c0 * 2, buf.data_ptr() + y0 * 2
+        d.w, d.scale, d.shift = w.data_ptr(), sc[i].data_ptr(), sh[i].data_ptr()
+        d.batch, d.h, d.w_in, d.cin, d.cout, d.x_ld, d.y_ld = B, H, W, ci, 32, ld, ld
+        d.ksize, d.stride, d.act, d.dtype, d.w_packed = 3, 1, 1, engine.BF16, packed
+        return d
+    got, ref = x.clone(), x.clone()
+    f1, f2 = engine._pack_fragments(w1, 1, cin * 2), engine._pack_fragments(w2, 1, 64)
+    da, db = desc(got, 0, cin, f1, 0, cin, 1), desc(got, cin, cin + 32, f2, 1, 32, 1)
+    assert _lib.lib.odamd_conv_chain_pair_supported(C.byref(da), C.byref(db)) == 1
+    _lib.check(_lib.lib.odamd_conv_chain_pair_forward(C.byref(da), C.byref(db), st), 'pair')
+    for d in (desc(ref, 0, cin, w1, 0, cin, 0), desc(ref, cin, cin + 32, w2, 1, 32, 0)):
+        _lib.check(_lib.lib.odamd_conv_forward(C.byref(d), st), 'conv')
+    torch.cuda.synchronize()
+    a, b = got.float().cpu().numpy(), ref.float().cpu().numpy()
+    assert np.array_equal(a[..., :cin], b[..., :cin]) and np.array_equal(a[..., cin + 64:], b[..., cin + 64:])   # untouched
+    for lo in (cin, cin + 32):
+        u, v = a[..., lo:lo + 32], b[..., lo:lo + 32]
+        assert np.abs(u - v).max() <= 2e-2 * np.abs(v).max(), (lo, np.abs(u - v).max())
+        assert (u != v).mean() < 0.02, (lo, (u != v).mean())
+    # a second convolution that does not read the first one's output is refused
+    db.x = got.data_ptr()
+    assert _lib.lib.odamd_conv_chain_pair_supported(C.byref(da), C.byref(db)) == 0
+    assert _lib.lib.odamd_conv_chain_pair_forward(C.byref(da), C.byref(db), st) != 0
+
+
 def test_block_golden_f32(od, golden):
     """Same blocks and inputs as the fixtures recorded from the reference."""
     engine, layer, _ = od

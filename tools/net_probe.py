@@ -1,5 +1,5 @@
-"""Whole forwards back to back (HIP events around N of them), with and without the side-branch stream; and the
-pipelined detection step with both settings."""
+"""Whole forwards back to back (HIP events around N of them) with an engine switch off and on, twice; and the pipelined
+detection step with both settings.  usage: net_probe.py [batch] [SWITCH]   (SIDE_STREAMS, FUSE_CHAIN, FUSE_MP ...)"""
 import os
 import sys
 import torch
@@ -10,11 +10,12 @@ from objectdetection_amd.predict import detect_pipeline
 from oracle import patterns
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+switch = sys.argv[2] if len(sys.argv) > 2 else 'SIDE_STREAMS'
 args = patterns.default_args(input_size=640, output_class=80)
 engine.set_compute_dtype('bf16')
 x = torch.rand(batch, 3, 640, 640).cuda()
 for side in (False, True, False, True):
-    engine.SIDE_STREAMS = side
+    setattr(engine, switch, side)
     torch.manual_seed(999)
     m = yolov7(args).cuda().eval()
     for _ in range(5):
@@ -37,5 +38,5 @@ for side in (False, True, False, True):
     pipe.synchronize()
     e1.record()
     torch.cuda.synchronize()
-    print(f'side streams {side}: network alone {net:.3f} ms per forward, pipelined step {e0.elapsed_time(e1) / 50:.3f} ms', flush=True)
+    print(f'{switch} {side}: network alone {net:.3f} ms per forward, pipelined step {e0.elapsed_time(e1) / 50:.3f} ms', flush=True)
     del m, pipe
