@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <type_traits>
 
+#include <atomic>
 #include "common.h"
 #include "odamd.h"
 
@@ -1858,6 +1859,24 @@ struct WresConfig { int kch, cgw, nbuf; };
 static int g_lab_no_wres = 0;
 WresConfig g_lab_wres = {};
 #endif
+// Compute units of the current device rounded down to whole XCD shares of 8 (0 when there is no device); queried once
+// per device, the cached value is the same whoever writes it first.
+int device_cus8() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (!n) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return 0;
+        n = n / 8 * 8;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+// one workgroup per compute unit, 8 walkers (one per XCD) per channel block at least: can the device hold them?
+bool wres_fits(int cout, int cgw) { return device_cus8() / (cout / (128 * cgw)) / 8 * 8 >= 8; }
+
 WresConfig wres_config(const ConvP& p, int ks, int stride, int dtype) {
     WresConfig none = {};
     if (dtype != ODAMD_DTYPE_BF16 || ks != 1 || stride != 1 || p.pool || p.upz || p.nchw || p.accum || !p.scale || !p.shift)
@@ -1874,10 +1893,14 @@ WresConfig wres_config(const ConvP& p, int ks, int stride, int dtype) {
     if (g_lab_wres.nbuf) nbuf = g_lab_wres.nbuf;
     if (g_lab_wres.cgw == 1 && (p.Cin == 256 || p.Cin == 512)) return {p.Cin / 256, 1, nbuf};
 #endif
-    if (p.Cin == 256) return {1, p.Cout % 256 == 0 ? 2 : 1, nbuf};
-    if (p.Cin == 512) return {2, p.Cout % 256 == 0 ? 2 : 1, nbuf};
-    if (p.Cin == 1024) return {4, 1, nbuf};
-    return none;
+    // a device with too few compute units for the layer's channel blocks (a partition, or very many output channels)
+    // gets no packed form here, so that the caller packs for a kernel that can be launched
+    WresConfig g = none;
+    if (p.Cin == 256) g = {1, p.Cout % 256 == 0 ? 2 : 1, nbuf};
+    else if (p.Cin == 512) g = {2, p.Cout % 256 == 0 ? 2 : 1, nbuf};
+    else if (p.Cin == 1024) g = {4, 1, nbuf};
+    if (g.kch && !wres_fits(p.Cout, g.cgw)) return none;
+    return g;
 }
 
 template <int KCH, int CGW, int NBUF, bool ACT>
@@ -1890,20 +1913,13 @@ int launch_wres(const ConvP& c, hipStream_t st) {
     p.ybytes = (unsigned)(((size_t)p.npix - 1) * p.y_ld * 2 + (size_t)c.Cout * 2);
     const size_t lds = (size_t)NBUF * WRES_UNIT + 2 * 128 * CGW * sizeof(float) + 4 * 32 * (CGW * 64 + 16);
     auto k = conv1x1_wres_kernel<KCH, CGW, NBUF, ACT>;
-    static int cus[64];                      // compute units per device; one workgroup each (the ring fills the LDS)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
-    if (!cus[dev]) {
-        if (lds > 160 * 1024) return ODAMD_E_SHAPE;
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return (int)hipGetLastError();
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return (int)hipErrorInvalidDevice;
-        cus[dev] = n / 8 * 8;
-    }
+    if (lds > 160 * 1024) return ODAMD_E_SHAPE;
+    if (odamd_ensure_lds((const void*)k, lds) != hipSuccess) return (int)hipGetLastError();
+    const int cus = device_cus8();           // one workgroup per compute unit (the ring fills the LDS)
+    if (!cus) return (int)hipErrorInvalidDevice;
     // walkers: a multiple of 8 (one share per XCD), at most one workgroup per compute unit, no more than tiles
-    int nwalk = cus[dev] / p.ncb / 8 * 8;
-    if (nwalk < 8) return ODAMD_E_SHAPE;
+    int nwalk = cus / p.ncb / 8 * 8;
+    if (nwalk < 8) return ODAMD_E_SHAPE;     // wres_config does not offer the kernel then
     const int need = (p.ntiles + 7) / 8 * 8;
     if (nwalk > need) nwalk = need;
     p.nwalk = nwalk;
