@@ -213,8 +213,9 @@ class detect_pipeline:
         self.anchor = anchor if anchor is not None else model.decode.anchor
         self.input_size = input_size if input_size is not None else model.decode.input_size
         self.splits = splits
-        self.net_streams = [torch.cuda.Stream() for _ in range(splits)]
-        self.post_streams = [torch.cuda.Stream() for _ in range(splits)]
+        dev = torch.cuda.current_device()
+        self.net_streams = [engine.shared_stream(dev, f'net{i}') for i in range(splits)]
+        self.post_streams = [engine.shared_stream(dev, f'post{i}') for i in range(splits)]
         self.slot = 0
         self.heads_free = {}                # (slot, split) -> event: post-processing has finished reading those heads
 

@@ -954,7 +954,7 @@ class TrainPlan:
 
     def _side_stream(self):
         if getattr(self, '_side', None) is None:
-            self._side = torch.cuda.Stream(device=self.dev)
+            self._side = engine.shared_stream(self.dev, 'side')
             self._events = {}
         return self._side
 

@@ -2,7 +2,7 @@
 # Collects the profile summaries kept under profiles/ (run on the GPU box from the repository root):
 #   1. rocprofv3 --kernel-trace --stats of the default bench.py command and of its inference leg alone
 #   2. three separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ counters) over tools/pmc_target.py
-#   3. the per-layer HIP-event table
+#   3. the per-layer HIP-event tables (preset s, preset l, one bf16 training step)
 # usage: tools/collect_profiles.sh TAG   (outputs gpurun_out/profiles/TAG_*)
 set -o pipefail
 TAG=${1:-rX}
@@ -14,6 +14,8 @@ export TMPDIR=/tmp
 cd /tmp || exit 1
 
 timeout -k 10 200 python3 "$ROOT/tools/layer_profile.py" 64 bf16 > "$OUT/${TAG}_layers_bf16_batch64.txt" 2>/dev/null || exit 1
+timeout -k 10 200 python3 "$ROOT/tools/layer_profile.py" 64 bf16 l > "$OUT/${TAG}_layers_l_bf16_batch64.txt" 2>/dev/null || exit 1
+timeout -k 10 200 python3 "$ROOT/tools/train_layer_profile.py" 1 > "$OUT/${TAG}_train_layers_bf16.txt" 2>/dev/null || exit 1
 echo "layers done"
 
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/bench" -o bench -- python3 "$ROOT/bench.py" \

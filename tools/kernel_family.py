@@ -31,6 +31,8 @@ def family(name, conv_only=False):
         return 'conv1x1_s1_c128' if ks == 1 else 'conv3x3_s%d_dma' % st
     if 'conv_mp_kernel' in name:
         return 'mp_1x1_pair'
+    if 'conv_pair_kernel' in name:
+        return 'conv3x3_pair'
     m = re.search(r'conv_s3_kernel<(\d+), (\d+), (\d+),', name)
     if m:
         _, cg, st = (int(v) for v in m.groups())
