@@ -436,8 +436,8 @@ maxpool_s1_bwd_bf16_kernel(const char* __restrict__ x, int x_ld, const char* __r
 // records.  54 comparisons per element instead of 25 + 81 + 169.
 // No atomics at all (float32 and bf16): the scatter "add the window's gradient at its
 // arg-max" becomes a gather.  Pass 1 and 2 as above, but pass 2 only RECORDS every window's arg-max pixel (and its
-// gradient) in LDS; in pass 3 every input element walks the windows that contain it, in a fixed order (k = 5, 9, 13,
-// rows, columns), and adds the gradients of those whose arg-max it is.  Float addition in a fixed order: the result is
+// gradient) in LDS; in pass 3 every input element walks the windows that can have picked it, in a fixed order (k = 5, 9, 13,
+// columns, rows), and adds the gradients of those whose arg-max it is.  Float addition in a fixed order: the result is
 // bitwise repeatable, which LDS / global float atomics are not as soon as three windows meet in one element.
 // One workgroup per (image, 16-byte channel vector); per element of the plane: value / sum (float), three gradients
 // (storage type), three row-maximum columns (bytes: W <= 255) and three arg-max pixels (16 bits: H * W <= 65535).
@@ -455,8 +455,9 @@ __host__ __device__ constexpr size_t spp_gather_bytes_per_pixel() {
     return (size_t)Vec<DT>::N * (sizeof(float) + 3 * sizeof(typename SppStore<DT>::T) + 3 + 3 * sizeof(uint16_t));
 }
 
-template <int DT>
-__global__ void __launch_bounds__(256)
+// NT threads: the passes are chains of dependent LDS reads, many waves hide their latency
+template <int DT, int NT>
+__global__ void __launch_bounds__(NT)
 spp_bwd_gather_kernel(const char* __restrict__ x, int x_ld, const char* __restrict__ dy5, const char* __restrict__ dy9,
                       const char* __restrict__ dy13, int dy_ld, char* __restrict__ dx, int dx_ld, int H, int W) {
     constexpr int N = Vec<DT>::N, ES = Vec<DT>::ES;
@@ -468,71 +469,105 @@ spp_bwd_gather_kernel(const char* __restrict__ x, int x_ld, const char* __restri
     uint16_t* argw = (uint16_t*)(dyv + 3 * ne);        // [3][hw][N]
     uint8_t* rcol = (uint8_t*)(argw + 3 * ne);         // [3][hw][N]
     const char* dys[3] = {dy5, dy9, dy13};
-    for (int p = threadIdx.x; p < hw; p += 256) {
-        float t[N];
-        Vec<DT>::load(x + (((size_t)b * hw + p) * x_ld) * ES + v * 16, t);
+    for (int i = threadIdx.x; i < 4 * hw; i += NT) {   // one 16-byte vector per thread and turn: x, then the three gradients
+        const int which = i / hw, p = i - which * hw;
+        if (which == 0) {
+            float t[N];
+            Vec<DT>::load(x + (((size_t)b * hw + p) * x_ld) * ES + v * 16, t);
 #pragma unroll
-        for (int e = 0; e < N; ++e) val[p * N + e] = t[e];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const char* g = dys[k] + (((size_t)b * hw + p) * dy_ld) * ES + v * 16;
-#pragma unroll
-            for (int e = 0; e < N; ++e) dyv[k * ne + p * N + e] = ((const S*)g)[e];
+            for (int e = 0; e < N; ++e) val[p * N + e] = t[e];
+        } else {
+            const char* g = dys[which - 1] + (((size_t)b * hw + p) * dy_ld) * ES + v * 16;
+            const uint4 raw = *(const uint4*)g;
+            *(uint4*)(dyv + (which - 1) * ne + p * N) = raw;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < ne; i += 256) {      // pass 1: leftmost row maxima of widths 5, 9, 13
+    // The loops below have compile-time trip counts and clamped coordinates (a position outside the plane reads a valid
+    // slot and counts as -inf), so that the compiler issues a pass's LDS reads together instead of one per iteration.
+    for (int i = threadIdx.x; i < ne; i += NT) {       // pass 1: leftmost row maxima of widths 5, 9, 13
         const int e = i % N, p = i / N;
         const int oy = p / W, ox = p - oy * W;
+        float t[13];
+#pragma unroll
+        for (int d = -6; d <= 6; ++d) {
+            const int gx = ox + d;
+            const float q = val[(oy * W + min(max(gx, 0), W - 1)) * N + e];
+            t[d + 6] = (gx >= 0 && gx < W) ? q : -INFINITY;
+        }
         float m5 = -INFINITY, m9 = -INFINITY, m13 = -INFINITY;
         int c5 = ox, c9 = ox, c13 = ox;
-        for (int gx = max(ox - 6, 0); gx <= min(ox + 6, W - 1); ++gx) {
-            const float t = val[(oy * W + gx) * N + e];
-            const int d = abs(gx - ox);
-            if (t > m13) { m13 = t; c13 = gx; }
-            if (d <= 4 && t > m9) { m9 = t; c9 = gx; }
-            if (d <= 2 && t > m5) { m5 = t; c5 = gx; }
+#pragma unroll
+        for (int d = -6; d <= 6; ++d) {
+            const float q = t[d + 6];
+            if (q > m13) { m13 = q; c13 = ox + d; }
+            if (d >= -4 && d <= 4 && q > m9) { m9 = q; c9 = ox + d; }
+            if (d >= -2 && d <= 2 && q > m5) { m5 = q; c5 = ox + d; }
         }
         rcol[i] = (uint8_t)c5; rcol[ne + i] = (uint8_t)c9; rcol[2 * ne + i] = (uint8_t)c13;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < ne; i += 256) {      // pass 2: first row holding the window maximum
+    for (int i = threadIdx.x; i < ne; i += NT) {       // pass 2: first row holding the window maximum
         const int e = i % N, p = i / N;
         const int oy = p / W, ox = p - oy * W;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
+            constexpr int RMAX = 6;
             const int rad = 2 + 2 * k;
+            int col[2 * RMAX + 1];
+            float t[2 * RMAX + 1];
+#pragma unroll
+            for (int d = -RMAX; d <= RMAX; ++d)
+                if (d >= -rad && d <= rad) col[d + RMAX] = rcol[k * ne + (min(max(oy + d, 0), H - 1) * W + ox) * N + e];
+#pragma unroll
+            for (int d = -RMAX; d <= RMAX; ++d)
+                if (d >= -rad && d <= rad) {
+                    const int gy = oy + d;
+                    const float q = val[(min(max(gy, 0), H - 1) * W + col[d + RMAX]) * N + e];
+                    t[d + RMAX] = (gy >= 0 && gy < H) ? q : -INFINITY;
+                }
             float m = -INFINITY;
             int arg = p;
-            for (int gy = max(oy - rad, 0); gy <= min(oy + rad, H - 1); ++gy) {
-                const int c = rcol[k * ne + (gy * W + ox) * N + e];
-                const float t = val[(gy * W + c) * N + e];
-                if (t > m) { m = t; arg = gy * W + c; }
-            }
+#pragma unroll
+            for (int d = -RMAX; d <= RMAX; ++d)
+                if (d >= -rad && d <= rad && t[d + RMAX] > m) { m = t[d + RMAX]; arg = (oy + d) * W + col[d + RMAX]; }
             argw[k * ne + i] = (uint16_t)arg;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < ne; i += 256) {      // pass 3: gather, fixed order
+    for (int i = threadIdx.x; i < ne; i += NT) {       // pass 3: gather, fixed order
         const int e = i % N, p = i / N;
         const int py = p / W, px = p - py * W;
         float sum = 0.0f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
+            constexpr int RMAX = 6;
             const int rad = 2 + 2 * k;
             const uint16_t* aw = argw + k * ne + e;
             const S* dv = dyv + k * ne + e;
-            for (int wy = max(py - rad, 0); wy <= min(py + rad, H - 1); ++wy)
-                for (int wx = max(px - rad, 0); wx <= min(px + rad, W - 1); ++wx) {
-                    const int q = (wy * W + wx) * N;
-                    if (aw[q] == (uint16_t)p) sum += SppStore<DT>::get(dv[q]);
+            // a window centred in column wx can only pick this element when the leftmost maximum of ITS segment of row py
+            // is column px (one column in 2 rad + 1 on average): only those columns are walked down
+            const uint8_t* rc = rcol + k * ne + e;
+            int pick[2 * RMAX + 1];
+#pragma unroll
+            for (int d = -RMAX; d <= RMAX; ++d)
+                if (d >= -rad && d <= rad) pick[d + RMAX] = rc[(py * W + min(max(px + d, 0), W - 1)) * N];
+#pragma unroll
+            for (int d = -RMAX; d <= RMAX; ++d)
+                if (d >= -rad && d <= rad) {
+                    const int wx = px + d;
+                    if (wx < 0 || wx >= W || pick[d + RMAX] != px) continue;
+                    for (int wy = max(py - rad, 0); wy <= min(py + rad, H - 1); ++wy) {
+                        const int q = (wy * W + wx) * N;
+                        if (aw[q] == (uint16_t)p) sum += SppStore<DT>::get(dv[q]);
+                    }
                 }
         }
         // every element writes its own slot; nobody reads `val` as values any more (pass 2 is behind the barrier)
         val[i] = sum;
     }
     __syncthreads();
-    for (int p = threadIdx.x; p < hw; p += 256) {
+    for (int p = threadIdx.x; p < hw; p += NT) {
         float t[N];
         char* d = dx + (((size_t)b * hw + p) * dx_ld) * ES + v * 16;
         Vec<DT>::load(d, t);
@@ -1623,14 +1658,16 @@ int odamd_spp_backward(const void* x, int x_ld, const void* dy5, const void* dy9
     if (aligned && w <= 255 && (size_t)h * w <= 65535 && lds <= 160 * 1024 && batch <= 65535) {
         const dim3 grid(c / per, batch);
         if (dtype == ODAMD_DTYPE_F32) {
-            auto k = spp_bwd_gather_kernel<ODAMD_DTYPE_F32>;
+            constexpr int NT = 512;
+            auto k = spp_bwd_gather_kernel<ODAMD_DTYPE_F32, NT>;
             if (odamd_ensure_lds((const void*)k, lds) != hipSuccess) return (int)hipGetLastError();
-            k<<<grid, 256, lds, (hipStream_t)stream>>>((const char*)x, x_ld, (const char*)dy5, (const char*)dy9, (const char*)dy13, dy_ld,
+            k<<<grid, NT, lds, (hipStream_t)stream>>>((const char*)x, x_ld, (const char*)dy5, (const char*)dy9, (const char*)dy13, dy_ld,
                                                         (char*)dx, dx_ld, h, w);
         } else {
-            auto k = spp_bwd_gather_kernel<ODAMD_DTYPE_BF16>;
+            constexpr int NT = 1024;
+            auto k = spp_bwd_gather_kernel<ODAMD_DTYPE_BF16, NT>;
             if (odamd_ensure_lds((const void*)k, lds) != hipSuccess) return (int)hipGetLastError();
-            k<<<grid, 256, lds, (hipStream_t)stream>>>((const char*)x, x_ld, (const char*)dy5, (const char*)dy9, (const char*)dy13, dy_ld,
+            k<<<grid, NT, lds, (hipStream_t)stream>>>((const char*)x, x_ld, (const char*)dy5, (const char*)dy9, (const char*)dy13, dy_ld,
                                                         (char*)dx, dx_ld, h, w);
         }
         return (int)hipGetLastError();
