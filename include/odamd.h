@@ -206,7 +206,9 @@ int odamd_conv_weight_layout(const odamd_conv_desc* d, int* cout_groups, int* ch
  * maxpool0(x), cbs2 on x): both read the same tensor, the largest of the block, which this entry point fetches
  * once.  `pooled` describes cbs1 (in_pool2 = 1, output at half resolution), `plain` cbs2; both must name the same
  * input (x, batch, h, w_in, cin, x_ld), bf16, plain weights, SiLU.  The fused form exists for whole 8 x 16 patches
- * (h % 8 == 0, w_in % 16 == 0), 32 / 64 / 128 input channels and 32 / 64 / 128 output channels per branch:
+ * (h % 8 == 0, w_in % 16 == 0), 32 / 64 / 128 input channels and 32 / 64 / 128 output channels per branch, and for
+ * whole 8 x 8 patches (h % 8 == 0, w_in % 8 == 0) with 256 input channels and 128 + 128 output channels (input
+ * channels walked in chunks, the weights streamed with them):
  * odamd_conv_mp_supported returns 1 then (pointers are ignored by the query), and odamd_conv_mp_forward gives the
  * same results as the two odamd_conv_forward calls.  Otherwise the forward call returns ODAMD_E_SHAPE. */
 int odamd_conv_mp_supported(const odamd_conv_desc* pooled, const odamd_conv_desc* plain);

@@ -766,6 +766,7 @@ __device__ __attribute__((aligned(64))) const unsigned char g_zero_line[64] = {}
 #include "conv_s3.h"
 #include "conv_wres.h"
 #include "conv_mp.h"
+#include "conv_mpk.h"
 #include "conv_pair.h"
 
 // ------------------------------------------------------------------------------------------
@@ -2005,6 +2006,50 @@ int dispatch_mp(const odamd_conv_desc* a, const odamd_conv_desc* b, hipStream_t 
     return ODAMD_E_SHAPE;
 }
 
+// ---- the same pair for 256 / 512 input channels: input channels in chunks, weights streamed (conv_mpk.h) -----------
+bool mpk_pair_ok(const odamd_conv_desc* a, const odamd_conv_desc* b) {
+    if (!a || !b) return false;
+    if (a->dtype != ODAMD_DTYPE_BF16 || b->dtype != ODAMD_DTYPE_BF16) return false;
+    if (a->ksize != 1 || b->ksize != 1 || a->stride != 1 || b->stride != 1) return false;
+    if (!a->in_pool2 || b->in_pool2 || a->out_nchw_f32 || b->out_nchw_f32 || a->in_upzero2 || b->in_upzero2 || a->accumulate ||
+        b->accumulate || a->w_packed || b->w_packed || a->act != 1 || b->act != 1 || !a->scale || !a->shift || !b->scale || !b->shift)
+        return false;
+    if (a->x != b->x || a->batch != b->batch || a->h != b->h || a->w_in != b->w_in || a->cin != b->cin || a->x_ld != b->x_ld) return false;
+    if (a->h % 8 || a->w_in % 8) return false;
+    if (a->cin != 256 || b->cout != 128 || a->cout != 128) return false;      // where the fused form measured ahead (conv_mpk.h)
+    const long long npix = (long long)a->batch * a->h * a->w_in;
+    if (npix * b->y_ld * 2 >= (1ll << 31) || (npix / 4) * a->y_ld * 2 >= (1ll << 31) || npix >= (1ll << 26)) return false;
+    if (a->y_ld < a->cout || b->y_ld < b->cout || (a->y_ld * 2) % 16 || (b->y_ld * 2) % 16 || (a->x_ld * 2) % 16) return false;
+    return true;
+}
+
+template <int CGW, int C1W, int CK>
+int launch_mpk(const odamd_conv_desc* a, const odamd_conv_desc* b, hipStream_t st) {
+    MpkP p = {};
+    p.x = (const char*)a->x;
+    p.w2 = (const char*)b->w; p.scale2 = b->scale; p.shift2 = b->shift; p.y2 = (char*)b->y;
+    p.w1 = (const char*)a->w; p.scale1 = a->scale; p.shift1 = a->shift; p.y1 = (char*)a->y;
+    p.B = a->batch; p.H = a->h; p.W = a->w_in; p.cbytes = a->cin * 2; p.x_ld = a->x_ld;
+    p.y2_ld = b->y_ld; p.y1_ld = a->y_ld;
+    p.patches_x = p.W / 8; p.patches_y = p.H / 8;
+    p.npatches = p.B * p.patches_x * p.patches_y;
+    p.npairs = (p.npatches + 1) / 2;
+    const size_t npix = (size_t)p.B * p.H * p.W;
+    p.y2bytes = (unsigned)((npix - 1) * p.y2_ld * 2 + (size_t)b->cout * 2);
+    p.y1bytes = (unsigned)((npix / 4 - 1) * p.y1_ld * 2 + (size_t)a->cout * 2);
+    const size_t staging = (size_t)(128 + 32 + 64 * CGW + 128 * C1W) * (CK + 16);
+    const size_t slices = (size_t)4 * 32 * ((CGW > C1W ? CGW : C1W) * 128 + 16);
+    const size_t lds = staging > slices ? staging : slices;
+    auto k = conv_mpk_kernel<CGW, C1W, CK>;
+    if (odamd_ensure_lds((const void*)k, lds) != hipSuccess) return (int)hipGetLastError();
+    int grid = lds <= 80 * 1024 ? 512 : 256;
+    if (grid > p.npairs) grid = p.npairs;
+    k<<<grid, 256, lds, st>>>(p);
+    return (int)hipGetLastError();
+}
+
+int dispatch_mpk(const odamd_conv_desc* a, const odamd_conv_desc* b, hipStream_t st) { return launch_mpk<2, 1, 128>(a, b, st); }
+
 // ---- two chained 3x3 convolutions with 32 channels between and after them in one launch (conv_pair.h) ----------
 // `a`: the first convolution, `b`: the second, which reads exactly what `a` writes.
 bool chain_pair_ok(const odamd_conv_desc* a, const odamd_conv_desc* b) {
@@ -2213,7 +2258,7 @@ int odamd_conv_forward(const odamd_conv_desc* d, void* stream) {
 int odamd_conv_mp_supported(const odamd_conv_desc* pooled, const odamd_conv_desc* plain) {
     ConvP pa, pb;
     if (fill_conv_params(pooled, &pa, false) != ODAMD_OK || fill_conv_params(plain, &pb, false) != ODAMD_OK) return 0;
-    return mp_pair_ok(pooled, plain) ? 1 : 0;
+    return (mp_pair_ok(pooled, plain) || mpk_pair_ok(pooled, plain)) ? 1 : 0;
 }
 
 int odamd_conv_mp_forward(const odamd_conv_desc* pooled, const odamd_conv_desc* plain, void* stream) {
@@ -2221,9 +2266,10 @@ int odamd_conv_mp_forward(const odamd_conv_desc* pooled, const odamd_conv_desc* 
     int rc = fill_conv_params(pooled, &pa, true);
     if (rc) return rc;
     if ((rc = fill_conv_params(plain, &pb, true))) return rc;
-    if (!mp_pair_ok(pooled, plain)) return ODAMD_E_SHAPE;
+    const bool wide = !mp_pair_ok(pooled, plain);
+    if (wide && !mpk_pair_ok(pooled, plain)) return ODAMD_E_SHAPE;
     if (((uintptr_t)pooled->y & 15) || ((uintptr_t)plain->y & 15)) return ODAMD_E_ALIGN;
-    return dispatch_mp(pooled, plain, (hipStream_t)stream);
+    return wide ? dispatch_mpk(pooled, plain, (hipStream_t)stream) : dispatch_mp(pooled, plain, (hipStream_t)stream);
 }
 
 int odamd_conv_chain_pair_supported(const odamd_conv_desc* first, const odamd_conv_desc* second) {
