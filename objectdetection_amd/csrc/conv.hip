@@ -2016,7 +2016,7 @@ bool mpk_pair_ok(const odamd_conv_desc* a, const odamd_conv_desc* b) {
         return false;
     if (a->x != b->x || a->batch != b->batch || a->h != b->h || a->w_in != b->w_in || a->cin != b->cin || a->x_ld != b->x_ld) return false;
     if (a->h % 8 || a->w_in % 8) return false;
-    if (a->cin != 256 || b->cout != 128 || a->cout != 128) return false;      // where the fused form measured ahead (conv_mpk.h)
+    if ((a->cin != 256 && a->cin != 128) || b->cout != 128 || a->cout != 128) return false;      // where the fused form measured ahead (conv_mpk.h)
     const long long npix = (long long)a->batch * a->h * a->w_in;
     if (npix * b->y_ld * 2 >= (1ll << 31) || (npix / 4) * a->y_ld * 2 >= (1ll << 31) || npix >= (1ll << 26)) return false;
     if (a->y_ld < a->cout || b->y_ld < b->cout || (a->y_ld * 2) % 16 || (b->y_ld * 2) % 16 || (a->x_ld * 2) % 16) return false;

@@ -128,7 +128,8 @@ def test_block_forward(od, kind, kw, shape, dtype):
 @pytest.mark.parametrize('in_,out_,shape', [(128, 128, (3, 128, 32, 48)), (64, 128, (2, 64, 16, 16)), (128, 256, (1, 128, 24, 32)),
                                             # 256 input channels: pairs of 8 x 8 patches, channels in chunks (an odd patch count,
                                             # a 40-wide map, enough pairs for several rounds per workgroup)
-                                            (256, 256, (1, 256, 24, 24)), (256, 256, (3, 256, 40, 40)), (256, 256, (40, 256, 80, 80))])
+                                            (256, 256, (1, 256, 24, 24)), (256, 256, (3, 256, 40, 40)), (256, 256, (40, 256, 80, 80)),
+                                            (128, 256, (5, 128, 40, 40))])
 def test_fused_mp_pair_equals_separate_launches(od, in_, out_, shape):
     """odamd_conv_mp_forward (both 1x1 convolutions of an mp block in one launch) against the two odamd_conv_forward
     launches it replaces, on the same weights and input: bit for bit."""
