@@ -595,26 +595,56 @@ class Plan:
                         break
             prev = self.lane[i]
         self.has_side = any(self.lane)
+        self._split_event = None
         self._events = []
 
-    def run(self, image):
-        """Enqueue the whole plan on the current stream. `image`: contiguous float32 NCHW."""
+    def first_launch_on_maps_up_to(self, h):
+        """Index of the first launch whose input map is at most `h` rows high (None if there is none)."""
+        for i, op in enumerate(self.launch_op):
+            sub = op.get('plain') or op.get('first') or op
+            x = sub.get('x')
+            if x is not None and x.h <= h:
+                return i
+        return None
+
+    def run(self, image, back=None, split=None):
+        """Enqueue the whole plan on the current stream. `image`: contiguous float32 NCHW.
+        `back`, `split`: launches from index `split` on go to the stream `back`, which first waits for the launches
+        before them (a pipeline runs the small-map half of one batch beside the large-map half of the next, see
+        predict.detect_pipeline); the caller orders later work after `back`.  Side branches stay on the main streams then
+        (a process has four hardware queues)."""
         self.refresh_weights()
         main = torch.cuda.current_stream()
         st = C.c_void_p(main.cuda_stream)
         side = side_st = None
-        if self.has_side:
+        if back is None or split is None or not 0 < split < len(self.launches):
+            back = split = None
+        use_side = self.has_side and back is None
+        if use_side:
             side = shared_stream(main.device, 'side')
             side_st = C.c_void_p(side.cuda_stream)
         img = image.data_ptr()
         nev, side_busy = 0, False
         for i, (fn, args, name, image_slot) in enumerate(self.launches):
+            if i == split:
+                if self._split_event is None:
+                    self._split_event = torch.cuda.Event()
+                self._split_event.record(main)
+                back.wait_event(self._split_event)
+                main, st = back, C.c_void_p(back.cuda_stream)
             if name == 'copy':
                 x, y = args
-                self.bufs[y.buf][..., y.c0:y.c0 + x.cphys].copy_(self.bufs[x.buf][..., x.c0:x.c0 + x.cphys])
+                with torch.cuda.stream(main):
+                    self.bufs[y.buf][..., y.c0:y.c0 + x.cphys].copy_(self.bufs[x.buf][..., x.c0:x.c0 + x.cphys])
                 continue
             if image_slot is not None:
                 args[image_slot] = img
+            if not use_side:
+                rc = fn(*args, st)
+                if rc:
+                    m = self.meta.get(i, {})
+                    check(rc, f"{name} #{i} {m.get('kernel', '')} {m.get('shape', '')}")
+                continue
             if self.fork[i] or (self.join[i] and side_busy):
                 if nev == len(self._events):
                     self._events.append(torch.cuda.Event())

@@ -168,17 +168,21 @@ class yolov7(torch.nn.Module):
             heads = self._emit(pb, (x.shape[2], x.shape[3]))
             plan = engine.Plan(pb)
             plan.head_ops = heads
+            # where the maps of stride 16 and coarser begin (model/yolov7.py:120: elan at 1/16 of the input): from there on
+            # a launch fills only part of the chip, and a pipeline may run that half beside the next batch's first half
+            plan.split_index = plan.first_launch_on_maps_up_to(x.shape[2] // 16)
             self._plans[key] = plan
         return plan
 
-    def head_tensors(self, x, slot=0):
-        """Run the network; returns the three raw head tensors (B, A, H, W, K) (views of plan memory)."""
+    def head_tensors(self, x, slot=0, back=None):
+        """Run the network; returns the three raw head tensors (B, A, H, W, K) (views of plan memory).
+        `back`: a stream for the second half of the launches (Plan.run); the tensors are then final on THAT stream."""
         if not x.is_cuda:
             raise RuntimeError('objectdetection_amd runs on the GPU only (no CPU fallback)')
         if self.training:
             raise RuntimeError('head_tensors runs the inference plan: call model.eval() first (training goes through forward())')
         plan = self._plan(x, slot)
-        plan.run(x.detach().float().contiguous())
+        plan.run(x.detach().float().contiguous(), back=back, split=plan.split_index if back is not None else None)
         k = 5 + self.output_class
         out = []
         for op in plan.head_ops:

@@ -186,6 +186,9 @@ class PostResultList:
         return out
 
 
+OVERLAP_HALVES = True      # detect_pipeline: small-map half of batch i beside the large-map half of batch i + 1
+
+
 class detect_pipeline:
     """Batched detection as a pipeline on several HIP streams: the network of batch i+1 runs while
     batch i is decoded, filtered, sorted and NMS-ed (predict.py:67-92 per image).  The network is
@@ -202,7 +205,7 @@ class detect_pipeline:
     """
 
     def __init__(self, model, confidence_threshold, iou_threshold, anchor=None, input_size=None, splits=1, max_keep=None,
-                 reuse_outputs=0):
+                 reuse_outputs=0, overlap_halves=None):
         """`max_keep`: bound of kept rows per image (sizes the output buffers; default: every row).
         `reuse_outputs` = n > 0: the result tensors of a submit are written over by the n-th submit after it (a
         serving loop that has read a result by then), instead of allocating (batch, max_keep, K) per submit."""
@@ -216,6 +219,11 @@ class detect_pipeline:
         dev = torch.cuda.current_device()
         self.net_streams = [engine.shared_stream(dev, f'net{i}') for i in range(splits)]
         self.post_streams = [engine.shared_stream(dev, f'post{i}') for i in range(splits)]
+        # the launches on the maps of stride 16 and coarser (about half of the network's time) fill only part of the chip:
+        # they run on a stream of their own, beside the large-map half of the NEXT batch (the two batches use different plans)
+        if overlap_halves is None:
+            overlap_halves = OVERLAP_HALVES
+        self.back_streams = [engine.shared_stream(dev, f'back{i}') for i in range(splits)] if overlap_halves else None
         self.slot = 0
         self.heads_free = {}                # (slot, split) -> event: post-processing has finished reading those heads
 
@@ -239,9 +247,10 @@ class detect_pipeline:
                 free = self.heads_free.get((slot, s))
                 if free is not None:
                     net.wait_event(free)
-                heads = self.model.head_tensors(xs, slot=(slot, s))
+                back = self.back_streams[s] if self.back_streams else None
+                heads = self.model.head_tensors(xs, slot=(slot, s), back=back)
                 ready = torch.cuda.Event()
-                ready.record(net)
+                ready.record(back if back is not None else net)
             with torch.cuda.stream(post):
                 post.wait_event(ready)
                 outs = self._outs.get((self._out_turn, s)) if self.reuse_outputs else None
@@ -259,5 +268,5 @@ class detect_pipeline:
         return parts[0] if n == 1 else PostResultList(parts)
 
     def synchronize(self):
-        for st in self.net_streams + self.post_streams:
+        for st in self.net_streams + self.post_streams + (self.back_streams or []):
             st.synchronize()

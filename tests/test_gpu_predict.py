@@ -78,7 +78,7 @@ def test_predict_batch_bf16_runs_and_is_consistent():
 
 
 def test_detect_pipeline_matches_sequential():
-    """Two-stream pipeline (alternating plans) returns exactly what the one-stream path returns."""
+    """The multi-stream pipeline (alternating plans) returns exactly what the one-stream path returns."""
     import torch
     from oracle import patterns
     from objectdetection_amd import engine, postprocess
@@ -96,15 +96,20 @@ def test_detect_pipeline_matches_sequential():
             r = postprocess.postprocess_heads(model.head_tensors(x), 128, args.anchor, 0.5, 0.5)
             torch.cuda.synchronize()
             want.append((r.count.cpu(), r.idx.cpu(), r.rows.cpu()))
-        pipe = detect_pipeline(model, 0.5, 0.5)
-        got = [pipe.submit(x) for x in batches]
-        pipe.synchronize()
-        for (cnt, idx, rows), r in zip(want, got):
-            assert torch.equal(cnt, r.count.cpu())
-            assert int(cnt.sum()) > 0
-            for b, n in enumerate(cnt.tolist()):
-                assert torch.equal(idx[b, :n], r.idx.cpu()[b, :n])
-                assert torch.equal(rows[b, :n], r.rows.cpu()[b, :n])
+        # with and without the second half of the launches on a stream of its own (beside the next batch's first half)
+        for halves in (True, False):
+            pipe = detect_pipeline(model, 0.5, 0.5, overlap_halves=halves)
+            assert (pipe.back_streams is not None) == halves
+            plan = model._plan(batches[0], (0, 0))
+            assert 0 < plan.split_index < len(plan.launches)
+            got = [pipe.submit(x) for x in batches]
+            pipe.synchronize()
+            for (cnt, idx, rows), r in zip(want, got):
+                assert torch.equal(cnt, r.count.cpu())
+                assert int(cnt.sum()) > 0
+                for b, n in enumerate(cnt.tolist()):
+                    assert torch.equal(idx[b, :n], r.idx.cpu()[b, :n])
+                    assert torch.equal(rows[b, :n], r.rows.cpu()[b, :n])
     finally:
         engine.set_compute_dtype(None)
 

@@ -11,11 +11,20 @@ from oracle import patterns
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 switch = sys.argv[2] if len(sys.argv) > 2 else 'SIDE_STREAMS'
+if len(sys.argv) > 3:         # e.g. SIDE_STREAMS=0: further engine switches held fixed for the whole run
+    for kv in sys.argv[3:]:
+        k, v = kv.split('=')
+        setattr(engine, k, bool(int(v)))
 args = patterns.default_args(input_size=640, output_class=80)
 engine.set_compute_dtype('bf16')
 x = torch.rand(batch, 3, 640, 640).cuda()
 for side in (False, True, False, True):
-    setattr(engine, switch, side)
+    if '.' in switch:
+        import importlib
+        modname, attr = switch.rsplit('.', 1)
+        setattr(importlib.import_module('objectdetection_amd.' + modname), attr, side)
+    else:
+        setattr(engine, switch, side)
     torch.manual_seed(999)
     m = yolov7(args).cuda().eval()
     for _ in range(5):
