@@ -25,6 +25,7 @@ from ._lib import lib, check
 F32, BF16 = 0, 1
 FUSE_MP = True                # both 1x1 convolutions of an mp block in one launch (bf16 plans)
 FUSE_FIRST2 = True     # bf16 plans run cbs0 + cbs1 as one launch when the widths are 16 and 32
+SPLIT_MAP_DIV = 32     # a pipeline's second stream takes a plan's launches from the first map of input size / SPLIT_MAP_DIV on
 FUSE_CHAIN = True      # two chained 3x3 convolutions with 32 channels between and after them in one launch (bf16 plans)
 SIDE_STREAMS = True    # side branches of a plan (heads, lateral 1x1 convolutions) run on a second HIP stream
 _TORCH_DT = {0: torch.float32, 1: torch.bfloat16}

@@ -168,9 +168,10 @@ class yolov7(torch.nn.Module):
             heads = self._emit(pb, (x.shape[2], x.shape[3]))
             plan = engine.Plan(pb)
             plan.head_ops = heads
-            # where the maps of stride 16 and coarser begin (model/yolov7.py:120: elan at 1/16 of the input): from there on
-            # a launch fills only part of the chip, and a pipeline may run that half beside the next batch's first half
-            plan.split_index = plan.first_launch_on_maps_up_to(x.shape[2] // 16)
+            # where the maps of stride 32 begin (model/yolov7.py:27-28: mp9, elan10): from there on most launches fill only
+            # part of the chip, and a pipeline may run them beside the next batch's large-map launches (measured at batch 64:
+            # any split between the first stride-16 and the first stride-32 launch gives the same step, later ones lose)
+            plan.split_index = plan.first_launch_on_maps_up_to(x.shape[2] // engine.SPLIT_MAP_DIV)
             self._plans[key] = plan
         return plan
 

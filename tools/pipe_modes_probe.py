@@ -16,8 +16,9 @@ engine.set_compute_dtype('bf16')
 x = torch.rand(batch, 3, 640, 640).cuda()
 print('GPU_MAX_HW_QUEUES', os.environ.get('GPU_MAX_HW_QUEUES'), flush=True)
 for rnd in range(rounds):
-    for side, halves in ((False, False), (False, True), (True, False), (True, True)):
+    for side, halves, div in ((False, False, 32), (False, True, 8), (False, True, 16), (False, True, 32), (True, False, 32)):
         engine.SIDE_STREAMS = side
+        engine.SPLIT_MAP_DIV = div
         torch.manual_seed(999)
         m = yolov7(args).cuda().eval()
         pipe = predict.detect_pipeline(m, 0.5, 0.5, anchor=args.anchor, input_size=640, overlap_halves=halves)
@@ -32,5 +33,5 @@ for rnd in range(rounds):
         pipe.synchronize()
         e1.record()
         torch.cuda.synchronize()
-        print(f'side {side!s:5} halves {halves!s:5}: pipelined step {e0.elapsed_time(e1) / 60:.3f} ms', flush=True)
+        print(f'side {side!s:5} halves {halves!s:5} split at maps of 1/{div}: pipelined step {e0.elapsed_time(e1) / 60:.3f} ms', flush=True)
         del pipe, m
