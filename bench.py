@@ -466,7 +466,7 @@ def main():
             'config': {'workload': f'YOLOv7-s {a.size}x{a.size} batch {a.batch} {a.dtype} inference + GPU decode/NMS '
                                    f'(headline configuration 2 of 5); C={a.classes}, conf {a.conf}, iou {a.iou}',
                        'global_batch': a.batch * world, 'parallelism': f'replicas x{world}',
-                       'pipeline': 'network(i+1) overlaps decode/NMS(i) on two HIP streams'},
+                       'pipeline': 'three HIP streams: large-map launches of batch i+1, small-map launches of batch i, decode/NMS of batch i-1 or i'},
             'roofline': roof,
             'network_ms_per_step': net_ms, 'network_ms_back_to_back': net_b2b_ms,
             'network_frac_of_per_layer_bound': sum(max(m['flops'] / (MFMA_PEAK_TFLOPS[a.dtype] * 1e12), m['bytes'] / (HBM_PEAK_GBS * 1e9))
