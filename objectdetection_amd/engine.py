@@ -179,6 +179,10 @@ class PlanBuilder:
 
 
 _shared_streams = {}
+# 'side' and 'back0' are never busy in the same run (a plan whose second half goes to 'back0' keeps its side branches on
+# the main streams, training plans do not run beside a pipeline): one stream serves both, which keeps a process that uses
+# the default stream, one pipeline and one training plan at exactly four streams = four hardware queues
+_STREAM_ALIAS = {'side': 'back0'}
 
 
 def shared_stream(device, role):
@@ -186,9 +190,10 @@ def shared_stream(device, role):
     and every stream beyond them shares a queue with another one, i.e. runs in order with it: a training plan whose
     weight-gradient stream lands on the queue of its main stream loses the overlap it was built for (measured: 16.8 ms
     against 14.9 ms per bf16 step once an inference pipeline and its plans had taken their streams).  Plans, pipelines
-    and training plans therefore draw from the same small set: 'side' (side branches / weight gradients), 'net<i>' and
-    'post<i>' (detect_pipeline)."""
+    and training plans therefore draw from the same small set: 'side' (side branches / weight gradients), 'net<i>',
+    'back<i>' and 'post<i>' (detect_pipeline)."""
     dev = torch.device(device)
+    role = _STREAM_ALIAS.get(role, role)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), role)
     st = _shared_streams.get(key)
     if st is None:
