@@ -1666,7 +1666,15 @@ DmaConfig dma_config(const ConvP& p, int ks, int stride, int dtype) {
         if ((long long)p.B * ((p.Ho * p.Wo + 63) / 64) * ((p.Cout + 63) / 64) >= (1 << 21)) return none;   // block index range of the kernel
         if (!choose_tile_s2(p.Ho, p.Wo, 4, dma_max_in_pix(3, 4, 2)).ok) return none;
         // measured at batch 64 (tools/micro/conv_lab.hip): 128 output channels per workgroup from 128 channels up
-        if (p.Cout >= 128) return {3, 4, 4, 2, 2, 32, 2, 2};
+        // ... and 256 output pixels per workgroup on 8 waves where such a tile exists: the stride-2 patch is four input pixels
+        // per output pixel, and the larger tile halves the weight bytes staged per pixel (128 -> 256 at 320 x 320 1.60 ->
+        // 1.37 ms, 256 -> 256 at 160 x 160 0.71 -> 0.62 ms, at 40 x 40 53 -> 48 us, 128 -> 128 at 80 x 80 63 -> 58 us)
+        if (p.Cout >= 128) {
+            // (only where that still leaves a workgroup per compute unit: 128 -> 128 at 40 x 40, 128 workgroups, 16 -> 22 us)
+            const long long big_tiles = (long long)p.B * ((p.Ho * p.Wo + 255) / 256) * ((p.Cout + 127) / 128);
+            if (big_tiles >= 256 && choose_tile_s2(p.Ho, p.Wo, 8, dma_max_in_pix(3, 8, 2)).ok) return {3, 8, 4, 4, 2, 32, 2, 2};
+            return {3, 4, 4, 2, 2, 32, 2, 2};
+        }
         return {3, 4, 2, 4, 1, 32, 2, 2};
     }
     if (stride != 1) return none;
@@ -1755,6 +1763,7 @@ int dispatch_dma(const ConvP& p, const DmaConfig& g, hipStream_t st) {
     ODAMD_DMA_CASE(1, 4, 4, 2, 2, 64, 3)
     ODAMD_DMA_S2_CASE(4, 2, 4, 1, 32, 2)
     ODAMD_DMA_S2_CASE(4, 4, 2, 2, 32, 2)
+    ODAMD_DMA_S2_CASE(8, 4, 4, 2, 32, 2)
 #ifdef LAB_DMA_S2_VARIANTS
     LAB_DMA_S2_VARIANTS
 #endif

@@ -14,7 +14,7 @@
     ODAMD_S3_CASE(2, 2, 2, 4, 640, 2) ODAMD_S3_CASE(4, 2, 1, 4, 256, 2) ODAMD_S3_CASE(4, 2, 1, 4, 192, 3) \
     ODAMD_S3_CASE(4, 2, 1, 4, 192, 2) ODAMD_S3_CASE(4, 1, 1, 4, 256, 2) ODAMD_S3_CASE(4, 1, 1, 4, 192, 3) \
     ODAMD_S3_CASE(4, 1, 1, 8, 384, 2)
-#define LAB_DMA_S2_VARIANTS ODAMD_DMA_S2_CASE(8, 2, 4, 1, 32, 2) ODAMD_DMA_S2_CASE(4, 2, 4, 1, 32, 3) ODAMD_DMA_S2_CASE(4, 2, 4, 1, 64, 2) ODAMD_DMA_S2_CASE(4, 2, 2, 2, 32, 2)
+#define LAB_DMA_S2_VARIANTS ODAMD_DMA_S2_CASE(8, 4, 2, 4, 32, 2) ODAMD_DMA_S2_CASE(8, 2, 4, 1, 32, 2) ODAMD_DMA_S2_CASE(4, 2, 4, 1, 32, 3) ODAMD_DMA_S2_CASE(4, 2, 4, 1, 64, 2) ODAMD_DMA_S2_CASE(4, 2, 2, 2, 32, 2)
 #define LAB_WRES_VARIANTS ODAMD_WRES_CASE(1, 2, 4) ODAMD_WRES_CASE(1, 1, 4) ODAMD_WRES_CASE(1, 2, 2) ODAMD_WRES_CASE(2, 2, 2) ODAMD_WRES_CASE(2, 1, 4) ODAMD_WRES_CASE(2, 1, 2)
 #include "../../objectdetection_amd/csrc/conv.hip"
 
@@ -140,7 +140,7 @@ int main(int argc, char** argv) {
             {-4, 1, 0, 0, 0, 0, 0},         // register-resident 1x1 kernel with one channel group per wave
             {-5, 4, 0, 0, 0, 0, 0}, {-5, 2, 0, 0, 0, 0, 0},   // ... with 4 / 2 ring buffers
             {-1, 4, 256, 3, 0, 0, 0}, {-1, 4, 256, 4, 0, 0, 0}, {-1, 8, 384, 3, 0, 0, 0}, {-2, 4, 640, 2, 0, 0, 0},   // conv_s3 variants: pg, npad, nbuf
-            {3, 8, 2, 4, 1, 32, 2, 2}, {3, 4, 2, 4, 1, 32, 3, 2}, {3, 4, 2, 4, 1, 64, 2, 2}, {3, 4, 4, 2, 2, 32, 2, 2}, {3, 4, 2, 2, 2, 32, 2, 2},
+            {3, 8, 4, 4, 2, 32, 2, 2}, {3, 8, 4, 2, 4, 32, 2, 2}, {3, 8, 2, 4, 1, 32, 2, 2}, {3, 4, 2, 4, 1, 32, 3, 2}, {3, 4, 2, 4, 1, 64, 2, 2}, {3, 4, 4, 2, 2, 32, 2, 2}, {3, 4, 2, 2, 2, 32, 2, 2},
             {3, 8, 2, 4, 1, 64, 2}, {3, 8, 2, 4, 1, 32, 3}, {3, 8, 2, 4, 1, 32, 2}, {3, 4, 2, 2, 2, 32, 3}, {3, 4, 2, 4, 1, 32, 3},
             {3, 4, 4, 2, 2, 32, 2}, {3, 8, 4, 4, 2, 32, 2}, {3, 8, 4, 4, 2, 32, 3}, {3, 8, 4, 2, 2, 32, 2}, {3, 8, 2, 4, 2, 32, 2}, {1, 8, 4, 2, 2, 128, 2}, {1, 4, 4, 2, 2, 128, 2},
             {1, 4, 4, 2, 2, 64, 3}, {1, 4, 4, 2, 2, 64, 2}, {1, 8, 4, 4, 2, 64, 3}, {1, 8, 8, 4, 2, 64, 2}, {1, 8, 4, 4, 2, 128, 2}};
