@@ -477,15 +477,21 @@ def main():
             'candidates_per_image': float(cand.float().mean()), 'kept_per_image': float(cnt.float().mean()),
             'kernel_families_ms': {k: round(v['ms'], 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])},
         }
+        def leg(name, fn):
+            # a side leg that fails (say, out of memory on a partitioned device) is reported in its own object and never
+            # costs the headline line
+            try:
+                out[name] = fn()
+            except Exception as e:                       # noqa: BLE001
+                out[name] = {'error': f'{type(e).__name__}: {e}'}
+                note(f'{name} leg failed: {e}')
+            torch.cuda.empty_cache()
         if world == 1 and not a.no_extra:
-            out['end_to_end'] = end_to_end_leg(model, a, margs, x_cpu)
-            torch.cuda.empty_cache()
-            out['dense'] = dense_leg(a, dev)
-            torch.cuda.empty_cache()
-            out['preset_l'] = preset_leg(a, dev, 'l', batch=a.batch)
-            torch.cuda.empty_cache()
+            leg('end_to_end', lambda: end_to_end_leg(model, a, margs, x_cpu))
+            leg('dense', lambda: dense_leg(a, dev))
+            leg('preset_l', lambda: preset_leg(a, dev, 'l', batch=a.batch))
         if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(model, a, margs, x_cpu)
+            leg('cpu_baseline', lambda: cpu_baseline(model, a, margs, x_cpu))
 
     if not a.no_train:
         # The training leg must never cost the inference line: if a collective stalls, rank 0 prints
@@ -503,13 +509,20 @@ def main():
         guard.start()
         del model, x
         tsteps = a.train_steps if a.train_steps is not None else min(a.steps, 40)
-        note('training leg f32')
-        train, tc_ = train_leg(a, dev, rank, world, dist, tsteps, max(a.warmup, 2))
-        note('training leg bf16')
-        del tc_
-        torch.cuda.empty_cache()
-        train_amp, tc_ = train_leg(a, dev, rank, world, dist, tsteps, max(a.warmup, 2), amp=True)
-        del tc_
+        try:
+            note('training leg f32')
+            train, tc_ = train_leg(a, dev, rank, world, dist, tsteps, max(a.warmup, 2))
+            note('training leg bf16')
+            del tc_
+            torch.cuda.empty_cache()
+            train_amp, tc_ = train_leg(a, dev, rank, world, dist, tsteps, max(a.warmup, 2), amp=True)
+            del tc_
+        except Exception as e:                           # noqa: BLE001
+            # like a stalled leg: the inference line is printed, the run fails
+            if rank == 0:
+                out['train'] = {'error': f'{type(e).__name__}: {e}'}
+                print(json.dumps(out), flush=True)
+            os._exit(3)
         guard.cancel()
         if rank == 0:
             out['train'] = train                 # float32: the reference default (--amp False)
