@@ -216,7 +216,7 @@ class detect_pipeline:
         self.anchor = anchor if anchor is not None else model.decode.anchor
         self.input_size = input_size if input_size is not None else model.decode.input_size
         self.splits = splits
-        dev = torch.cuda.current_device()
+        dev = next(model.parameters()).device        # the streams belong to the model's device, not to the current one
         self.net_streams = [engine.shared_stream(dev, f'net{i}') for i in range(splits)]
         self.post_streams = [engine.shared_stream(dev, f'post{i}') for i in range(splits)]
         # the launches on the maps of stride 16 and coarser (about half of the network's time) fill only part of the chip:
